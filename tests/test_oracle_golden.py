@@ -1,0 +1,149 @@
+"""Pin the CPU oracle (oracle/uresnet_oracle.py) to fixtures produced by the reference's own code.
+
+Fixtures: tests/golden/*.npz, written by tests/golden/make_golden.py from an in-memory import
+of /root/reference.  Tolerances: forward <= 1e-6 abs on log-probs
+(both sides are fp32 PyTorch-CPU; the only difference is op dispatch order), gradients
+<= 1e-5 relative on per-tensor L2 norms and sampled entries.
+"""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import uresnet_oracle as O
+from ubresnet_amd import synthetic
+
+torch.set_num_threads(min(8, os.cpu_count() or 1))
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def test_schema_matches_reference_keys(golden_dir):
+    for fn, schema in (("state_dict_keys_uresnet_ip16.txt", O.uresnet_schema(3, 1, 16, 16)),
+                       ("state_dict_keys_aspp_ip16.txt", O.aspp_resnet_schema(3, 3, 16))):
+        lines = open(os.path.join(golden_dir, fn)).read().split("\n")[:-1]
+        keys = [l.split(" ")[0] for l in lines]
+        assert keys == list(schema.keys())
+    sd = O.seeded_state_dict(O.uresnet_schema(3, 1, 16, 16), 42)
+    nparam = sum(v.numel() for k, v in sd.items() if O.is_param_key(k))
+    assert nparam == 18100931
+    assert sum(1 for k in sd if O.is_param_key(k)) == 165
+    sda = O.seeded_state_dict(O.aspp_resnet_schema(3, 3, 16), 44)
+    assert sum(v.numel() for k, v in sda.items() if O.is_param_key(k)) == 31577251
+
+
+@pytest.mark.parametrize("tag", ["2x1x64x64", "1x1x96x128"])
+def test_uresnet_forward_and_grads(golden_dir, tag):
+    g = _load(golden_dir, "uresnet_ip16_%s.npz" % tag)
+    B, C, H, W, seed0, wseed = [int(v) for v in g["meta"]]
+    sd = O.seeded_state_dict(O.uresnet_schema(3, C, 16, 16), wseed)
+    x, lab, wgt = synthetic.make_batch(B, H, W, seed0)
+    xt, lt, wt = torch.from_numpy(x), torch.from_numpy(lab), torch.from_numpy(wgt)
+    with torch.no_grad():
+        ev = O.uresnet_forward(sd, xt, train=False)
+    assert np.abs(ev.numpy() - g["logp_eval"]).max() <= 1e-6 * max(1.0, np.abs(g["logp_eval"]).max())
+    loss, grads, logp, ns = O.train_step_grads(O.uresnet_forward, sd, xt, lt, wt)
+    assert np.abs(logp.numpy() - g["logp_train"]).max() <= 2e-6 * max(1.0, np.abs(g["logp_train"]).max())
+    assert abs(float(loss) - float(g["loss"])) <= 1e-6 * abs(float(g["loss"]))
+    names = [str(n) for n in g["grad_names"]]
+    assert names == list(grads.keys())
+    for n, ref_norm in zip(names, g["grad_norms"]):
+        gv = grads[n].reshape(-1).numpy()
+        norm = np.sqrt((gv.astype(np.float64) ** 2).sum())
+        assert abs(norm - ref_norm) <= 1e-5 * ref_norm + 1e-7, n
+        rs = np.random.RandomState(7)
+        idx = np.sort(rs.choice(gv.shape[0], size=min(16, gv.shape[0]), replace=False))
+        assert np.abs(gv[idx] - g["gs__" + n]).max() <= 1e-5 * (np.abs(gv).max() + 1e-12) + 1e-7, n
+    for k in ("bn1", "bn10"):
+        assert np.abs(ns[k + ".running_mean"].numpy() - g[k + "_running_mean"]).max() <= 1e-6
+        assert np.abs(ns[k + ".running_var"].numpy() - g[k + "_running_var"]).max() <= 1e-5
+    assert int(ns["bn1.num_batches_tracked"]) == int(g["nbt"])
+
+
+def test_uresnet_four_classes_eval(golden_dir):
+    g = _load(golden_dir, "uresnet_ip16_nc4_1x1x64x96.npz")
+    B, C, H, W, seed0, wseed = [int(v) for v in g["meta"]]
+    sd = O.seeded_state_dict(O.uresnet_schema(4, C, 16, 16), wseed)
+    x, _, _ = synthetic.make_batch(B, H, W, seed0)
+    with torch.no_grad():
+        ev = O.uresnet_forward(sd, torch.from_numpy(x), train=False)
+    assert np.abs(ev.numpy() - g["logp_eval"]).max() <= 1e-6 * max(1.0, np.abs(g["logp_eval"]).max())
+
+
+def test_aspp_forward_and_grads(golden_dir):
+    g = _load(golden_dir, "aspp_ip16_1x3x64x96.npz")
+    B, C, H, W, seed0, wseed = [int(v) for v in g["meta"]]
+    sd = O.seeded_state_dict(O.aspp_resnet_schema(3, C, 16), wseed)
+    x, lab, wgt = synthetic.make_batch(B, H, W, seed0, planes=C)
+    xt, lt, wt = torch.from_numpy(x), torch.from_numpy(lab), torch.from_numpy(wgt)
+    with torch.no_grad():
+        ev = O.aspp_resnet_forward(sd, xt, train=False)
+    assert np.abs(ev.numpy() - g["logp_eval"]).max() <= 1e-6 * max(1.0, np.abs(g["logp_eval"]).max())
+    loss, grads, logp, _ = O.train_step_grads(O.aspp_resnet_forward, sd, xt, lt, wt)
+    assert abs(float(loss) - float(g["loss"])) <= 1e-6 * abs(float(g["loss"]))
+    for n, ref_norm in zip([str(n) for n in g["grad_names"]], g["grad_norms"]):
+        gv = grads[n].reshape(-1).numpy().astype(np.float64)
+        assert abs(np.sqrt((gv ** 2).sum()) - ref_norm) <= 2e-5 * ref_norm + 1e-7, n
+
+
+def test_blocks_and_loss(golden_dir):
+    g = _load(golden_dir, "blocks.npz")
+    for name, (cin, cout, stride) in {"id": (8, 8, 1), "proj": (8, 16, 1), "down": (8, 16, 2)}.items():
+        sd = O.seeded_state_dict(O._block_keys("b", cin, cout, stride), 50 + stride + cout)
+        x = torch.from_numpy(g["block_%s_x" % name])
+        with torch.no_grad():
+            tr = O.basic_block(sd, "b", x, stride, True, None)
+            ev = O.basic_block(sd, "b", x, stride, False, None)
+        assert np.abs(tr.numpy() - g["block_%s_train" % name]).max() <= 2e-6
+        assert np.abs(ev.numpy() - g["block_%s_eval" % name]).max() <= 2e-6
+    from collections import OrderedDict
+    sd = O.seeded_state_dict(OrderedDict([("d.deconv.weight", (16, 8, 4, 4))] + list(O._double_keys("d.res", 16, 8, 1).items())), 60)
+    with torch.no_grad():
+        ev = O.conv_transpose_layer(sd, "d", torch.from_numpy(g["ctl_x"]), torch.from_numpy(g["ctl_skip"]), False, None)
+        tr = O.conv_transpose_layer(sd, "d", torch.from_numpy(g["ctl_x"]), torch.from_numpy(g["ctl_skip"]), True, None)
+    assert np.abs(ev.numpy() - g["ctl_eval"]).max() <= 2e-6
+    assert np.abs(tr.numpy() - g["ctl_train"]).max() <= 2e-6
+    loss = O.pixelwise_nll(torch.from_numpy(g["loss_logp"]), torch.from_numpy(g["loss_target"]), torch.from_numpy(g["loss_pw"]))
+    assert abs(float(loss) - float(g["loss_value"])) <= 1e-6 * abs(float(g["loss_value"]))
+    # closed form: mean(-logp[target]*w), ignored pixels contribute 0 but stay in the denominator
+    lp, tg, pw = g["loss_logp"], g["loss_target"], g["loss_pw"]
+    acc = 0.0
+    for b in range(lp.shape[0]):
+        for i in range(lp.shape[2]):
+            for j in range(lp.shape[3]):
+                if tg[b, i, j] != -100:
+                    acc += -float(lp[b, tg[b, i, j], i, j]) * float(pw[b, i, j])
+    assert abs(acc / tg.size - float(g["loss_value"])) <= 1e-5 * abs(float(g["loss_value"]))
+
+
+def test_uresnet_512_summary(golden_dir):
+    """BASELINE config-1 shape (B=2, 512x512): sampled log-probs, argmax hash off low-margin pixels."""
+    g = _load(golden_dir, "uresnet_ip16_2x1x512x512_summary.npz")
+    B, C, H, W, seed0, wseed = [int(v) for v in g["meta"]]
+    sd = O.seeded_state_dict(O.uresnet_schema(3, C, 16, 16), wseed)
+    x, _, _ = synthetic.make_batch(B, H, W, seed0)
+    with torch.no_grad():
+        ev = O.uresnet_forward(sd, torch.from_numpy(x), train=False)
+    flat = ev.numpy().reshape(-1)
+    ref = g["sample_logp_eval"]
+    assert np.abs(flat[g["sample_idx"]] - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max())
+    am = ev.max(1)[1].numpy().astype(np.uint8)
+    if len(g["low_margin_idx"]) == 0:
+        assert hashlib.sha256(am.tobytes()).hexdigest() == str(g["argmax_sha256_eval"])
+    assert np.abs(np.bincount(am.reshape(-1), minlength=3) - g["class_counts_eval"]).sum() <= 2 * len(g["low_margin_idx"])
+
+
+def test_accuracy_and_confusion():
+    rs = np.random.RandomState(3)
+    out = torch.from_numpy(rs.standard_normal((2, 3, 8, 8)).astype(np.float32))
+    tgt = torch.from_numpy(rs.randint(0, 3, (2, 8, 8)).astype(np.int64))
+    acc = O.accuracy(out, tgt)
+    cm = O.confusion_matrix(out, tgt)
+    for c in range(3):
+        n = cm[c].sum().item()
+        assert abs(acc[c] - (100.0 * cm[c, c].item() / n if n else 0.0)) < 1e-9
+    assert abs(acc[3] - 100.0 * cm.diag().sum().item() / cm.sum().item()) < 1e-9
