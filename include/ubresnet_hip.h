@@ -1,0 +1,233 @@
+/*
+ * ubresnet_hip.h -- C ABI of libubresnet_hip.so (hand-written HIP kernels, gfx950 / MI355X).
+ *
+ * The reference (NuTufts/ubresnet) has no native code and no FFI: every FLOP of its hot path is
+ * a torch.nn layer call.  This header is the boundary a binding would
+ * target instead of those layer calls; each entry point cites the reference call it replaces.
+ * The Python host side (ubresnet_amd/_lib.py, ctypes) binds exactly these symbols.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless stated; `stream` is a hipStream_t passed as void*.
+ *   - activations are NHWC with explicit element strides (ubr_tensor); element type selected by
+ *     `dtype` (UBR_F32 / UBR_BF16 / UBR_F16); accumulation is always fp32; statistics are fp64.
+ *   - every function validates its arguments on the host and returns 0 on success or a
+ *     negative UBR_E* code; ubr_last_error() gives a message.  No function allocates,
+ *     frees or synchronises (safe under hipGraph capture), no global mutable state except
+ *     the per-thread error string.
+ */
+#ifndef UBRESNET_HIP_H
+#define UBRESNET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UBR_F32 0
+#define UBR_BF16 1
+#define UBR_F16 2
+
+#define UBR_OK 0
+#define UBR_EINVAL (-1)   /* bad argument / unsupported shape */
+#define UBR_ELAUNCH (-2)  /* hip launch error */
+
+#define UBR_MAX_TAPS 64
+
+/* Strided NHWC view: element (n,y,x,c) lives at p + n*sn + y*sy + x*sx + c (strides in elements). */
+typedef struct {
+  void* p;
+  int64_t sn, sy, sx;
+} ubr_tensor;
+
+/* Per-input-channel affine + clamp applied while the operand is loaded:
+ *   v = max(v*scale[c] + shift[c], lo[c]).
+ * This is how train-mode BatchNorm2d + ReLU are folded into the consumer
+ * (lo = 0 for ReLU, -FLT_MAX for none); all three NULL = identity.  Zero padding is applied
+ * AFTER the transform, as nn.Conv2d pads the BN/ReLU output. */
+typedef struct {
+  const float* scale;
+  const float* shift;
+  const float* lo;
+} ubr_chan_affine;
+
+/* ------------------------------------------------------------------------------------------
+ * Implicit-GEMM direct convolution on MFMA.  One descriptor covers:
+ *   nn.Conv2d k in {1,3,7}, stride 1/2, dilation 1/3/5  (models/common_layers.py:13-15,33;
+ *       models/ub_uresnet.py:41,60,64; models/ASPP_ResNet.py:199-220,275) forward,
+ *   nn.ConvTranspose2d k4 s2 p1 forward (models/common_layers.py:125) as 4 output phases,
+ *   and the data gradients of both (what autograd's ConvolutionBackward computes).
+ * out(oy,ox,co) = bias[co] + addend(oy,ox,co)
+ *               + sum_t sum_ci  xform(x)(oy*S + iy0 + dy[t], ox*S + ix0 + dx[t], ci) * w[wt[t]][ci][co]
+ * `w` is the packed image written by ubr_pack_weights.  `y` is a view of the output grid
+ * (OH x OW); phase decompositions pass a view with doubled strides.
+ * stats (optional): stats[co] += sum over the grid of out, stats[Cout+co] += sum of out^2
+ * (BatchNorm2d batch statistics, accumulated in fp64).
+ * epilogue = 1: fused nn.LogSoftmax(dim=1) (models/ub_uresnet.py:143): y.p is then a float*
+ * NCHW [N, Cout, OH, OW] buffer and Cout (= num_classes) <= 16.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t dtype;
+  int32_t N, H, W, Cin;      /* input tensor extent */
+  ubr_tensor x;
+  ubr_chan_affine xf;
+  const void* w;             /* packed weights */
+  int32_t Cout, Cout_pad;    /* Cout_pad = Cout rounded up to 16 (packed image width) */
+  int32_t ntaps;
+  int8_t dy[UBR_MAX_TAPS], dx[UBR_MAX_TAPS];
+  uint8_t wt[UBR_MAX_TAPS];  /* packed tap index used by tap t */
+  int32_t S, iy0, ix0;
+  int32_t OH, OW;            /* output grid */
+  ubr_tensor y;
+  ubr_tensor addend;         /* p == NULL: none */
+  const float* bias;         /* NULL: none */
+  double* stats;             /* NULL: none */
+  int32_t epilogue;          /* 0 store T NHWC, 1 log-softmax to fp32 NCHW */
+  int32_t tile_hint;         /* 0 auto */
+} ubr_conv_desc;
+
+int ubr_conv(const ubr_conv_desc* d, void* stream);
+
+/* Weight repack: fp32 master weights (PyTorch layouts) -> packed image for ubr_conv.
+ *   dst[t][ku][m][e] = (T) src[m*sm + (ku*CPU+e)*sk + tapidx[t]],  m < M (zero for M <= m < Mpad)
+ * forward orientation of Conv2d [Cout][Cin][kh][kw]: M=Cout, K=Cin, sm=Cin*kh*kw, sk=kh*kw;
+ * data-gradient orientation: M=Cin, K=Cout, sm=kh*kw, sk=Cin*kh*kw; ConvTranspose2d
+ * [Cin][Cout][4][4] likewise.  K beyond Kvalid is zero-filled up to Kpad (multiple of CPU). */
+int ubr_pack_weights(int dtype, const float* src, void* dst, int M, int Mpad, int Kvalid, int Kpad,
+                     int64_t sm, int64_t sk, int ntaps, const int32_t* tapidx_host, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Weight gradient (autograd ConvolutionBackward, weight part) on MFMA with pixels as K.
+ *   dW[t][co][ci] = sum_{n,oy,ox} g(n,oy,ox,co) * xform(x)(n, oy*S+iy0+dy[t], ox*S+ix0+dx[t], ci)
+ * Each workgroup writes an fp32 partial slab; ubr_wgrad_reduce sums slabs in a fixed order
+ * (bitwise reproducible) and scatters into the PyTorch weight-gradient layout:
+ *   dst[co*sm + ci*sk + tapidx[t]] (+)= sum_slabs
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t dtype;
+  int32_t N, H, W, Cin;
+  ubr_tensor x;
+  ubr_chan_affine xf;
+  int32_t GH, GW, Cout;      /* gradient grid and channels (Cout multiple of 16, padded) */
+  ubr_tensor g;
+  int32_t ntaps;
+  int8_t dy[UBR_MAX_TAPS], dx[UBR_MAX_TAPS];
+  int32_t S, iy0, ix0;
+  float* slabs;              /* workspace, >= ubr_wgrad_workspace() bytes */
+  int32_t nsplit;            /* number of pixel splits (slabs); from ubr_wgrad_plan */
+} ubr_wgrad_desc;
+
+/* returns the number of slabs the launch will use for this shape (>=1) and the workspace bytes */
+int ubr_wgrad_plan(const ubr_wgrad_desc* d, int32_t* nsplit, int64_t* workspace_bytes);
+int ubr_wgrad(const ubr_wgrad_desc* d, void* stream);
+int ubr_wgrad_reduce(const float* slabs, int nsplit, int ntaps, int Cout_pad, int Cin,
+                     int Cout_valid, int Cin_valid, float* dst, int64_t sm, int64_t sk,
+                     const int32_t* tapidx_host, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Stem: conv1 7x7 s1 p3 + bias on the caller's NCHW fp32 image (models/ub_uresnet.py:41,94;
+ * Cin in {1..4}), writing raw NHWC output and BatchNorm statistics; and its weight/bias grads.
+ * ---------------------------------------------------------------------------------------- */
+int ubr_stem_forward(int dtype, const float* x_nchw, int N, int Cin, int H, int W,
+                     const float* weight /*[Cout][Cin][7][7]*/, const float* bias, int Cout,
+                     ubr_tensor y, double* stats, void* stream);
+int ubr_stem_wgrad(int dtype, const float* x_nchw, int N, int Cin, int H, int W, ubr_tensor g, int Cout,
+                   float* partial /*workspace*/, int64_t partial_bytes, float* dweight, float* dbias,
+                   int accumulate, void* stream);
+int64_t ubr_stem_wgrad_workspace(int N, int Cin, int H, int W, int Cout);
+
+/* ------------------------------------------------------------------------------------------
+ * BatchNorm2d (eps, momentum from the module; e.g. models/common_layers.py:24)
+ * ---------------------------------------------------------------------------------------- */
+/* train: stats (fp64 sum, sumsq over `count` elements per channel) -> scale = gamma*invstd,
+ * shift = beta - mean*scale, mean, invstd; running stats updated with the unbiased variance. */
+int ubr_bn_finalize(const double* stats, double count, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                    float momentum, float eps, int C,
+                    float* scale, float* shift, float* mean, float* invstd, void* stream);
+/* eval: scale/shift from running statistics */
+int ubr_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, int C, float* scale, float* shift, void* stream);
+
+/* Backward of  a = max(bn(c), lo)  given g_a (sum of up to two tensors):
+ *   pass 1 (reduce): red[c] += sum g_y, red[C+c] += sum g_y*xhat      (g_y = g_a * [bn(c) > lo])
+ *   finalize       : dgamma, dbeta, and the per-channel constants of pass 2
+ *   pass 2 (apply) : g_c = scale * (g_y - k1 - xhat*k2)
+ * relu = 0 drops the mask (BatchNorm with no ReLU, e.g. bnpass, models/common_layers.py:50-51). */
+int ubr_bn_bwd_reduce(int dtype, int64_t npix, int C, const void* ga, int64_t ga_ps, const void* ga2, int64_t ga2_ps,
+                      const void* c, int64_t c_ps, const float* scale, const float* shift, const float* mean,
+                      const float* invstd, int relu, double* red, void* stream);
+int ubr_bn_bwd_finalize(const double* red, double count, const float* scale /*gamma*invstd*/, const float* invstd,
+                        int C, float* dgamma, float* dbeta, int accumulate, float* k1, float* k2, void* stream);
+int ubr_bn_bwd_apply(int dtype, int64_t npix, int C, const void* ga, int64_t ga_ps, const void* ga2, int64_t ga2_ps,
+                     const void* c, int64_t c_ps, const float* scale, const float* shift, const float* mean,
+                     const float* invstd, int relu, const float* k1, const float* k2,
+                     void* gc, int64_t gc_ps, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * BasicBlock tail (models/common_layers.py:47-56):
+ *   out = relu( relu(bn2(c2)) + shortcut ),  shortcut = bnpass(cb)  or  x
+ * forward; backward pass 1 (all per-channel reductions of both BatchNorms) and pass 2
+ * (g_c2, and g_cb or the identity-skip gradient g_skip = g_out*[out>0]).
+ * ---------------------------------------------------------------------------------------- */
+int ubr_block_tail_fwd(int dtype, int64_t npix, int C, const void* c2, int64_t c2_ps, const float* scale2,
+                       const float* shift2, const void* sc, int64_t sc_ps, const float* scale_b,
+                       const float* shift_b /*NULL => identity shortcut*/, void* out, int64_t out_ps, void* stream);
+int ubr_block_tail_bwd_reduce(int dtype, int64_t npix, int C, const void* go, int64_t go_ps, const void* go2, int64_t go2_ps,
+                              const void* out, int64_t out_ps, const void* c2, int64_t c2_ps,
+                              const float* scale2, const float* shift2, const float* mean2, const float* invstd2,
+                              const void* cb, int64_t cb_ps, const float* mean_b, const float* invstd_b,
+                              double* red2, double* red_b, void* stream);
+int ubr_block_tail_bwd_apply(int dtype, int64_t npix, int C, const void* go, int64_t go_ps, const void* go2, int64_t go2_ps,
+                             const void* out, int64_t out_ps, const void* c2, int64_t c2_ps,
+                             const float* scale2, const float* shift2, const float* mean2, const float* invstd2,
+                             const float* k1_2, const float* k2_2,
+                             const void* cb, int64_t cb_ps, const float* scale_b, const float* mean_b, const float* invstd_b,
+                             const float* k1_b, const float* k2_b,
+                             void* g_c2, int64_t g_c2_ps, void* g_sc, int64_t g_sc_ps, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * nn.MaxPool2d(3, stride, padding=1)  (models/ub_uresnet.py:44 stride 2; ASPP_ResNet.py:222 stride 1)
+ * forward reads the (optionally transformed) input, writes the pooled map and optionally the
+ * transformed input itself (`xcopy`, the skip tensor x0 of models/ub_uresnet.py:96);
+ * backward gathers g_pooled through the recomputed arg-max (first maximum in scan order,
+ * as ATen) and adds `g_extra` (gradient arriving through the skip connection).
+ * ---------------------------------------------------------------------------------------- */
+int ubr_maxpool_fwd(int dtype, int N, int H, int W, int C, int stride, const void* x, int64_t x_ps,
+                    ubr_chan_affine xf, void* pooled, int64_t p_ps, void* xcopy, int64_t xc_ps, void* stream);
+int ubr_maxpool_bwd(int dtype, int N, int H, int W, int C, int stride, const void* x, int64_t x_ps,
+                    ubr_chan_affine xf, const void* g_pooled, int64_t gp_ps, const void* g_extra, int64_t ge_ps,
+                    void* gx, int64_t gx_ps, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Head / loss
+ * ---------------------------------------------------------------------------------------- */
+/* nn.LogSoftmax backward fused with the NCHW->NHWC re-layout: g_logits (T, NHWC, Cpad=16 channels,
+ * zero padded) = g_logp - exp(logp) * sum_c g_logp */
+int ubr_logsoftmax_bwd(int dtype, int N, int C, int H, int W, const float* g_logp_nchw, const float* logp_nchw,
+                       void* g_logits, int64_t gl_ps, void* stream);
+/* PixelWiseNLLLoss.forward (training/pixelwise_nllloss.py:41-61): acc[0] += sum over pixels of
+ * -predict[b,target,h,w]*classw[target]*pixelweights ; loss = acc/(B*H*W) is formed by the caller. */
+int ubr_pixelwise_nll_fwd(const float* predict_nchw, const int64_t* target, const float* pixelweights,
+                          const float* classw /*NULL*/, int N, int C, int H, int W, int64_t ignore_index,
+                          double* acc, void* stream);
+int ubr_pixelwise_nll_bwd(const float* g_loss /*device scalar*/, const int64_t* target, const float* pixelweights,
+                          const float* classw, int N, int C, int H, int W, int64_t ignore_index,
+                          float* g_predict_nchw, void* stream);
+/* accuracy() (training/train_ubresnet2018_wlarcv2.py:509-566) in one pass: cm[true*C+pred] += 1
+ * with pred = first arg-max over channels (Tensor.max(1) tie-break). */
+int ubr_confusion(const float* logp_nchw, const int64_t* target, int N, int C, int H, int W,
+                  unsigned long long* cm, void* stream);
+
+/* per-channel sum over pixels of an NHWC tensor (conv bias gradients): out[c] (+)= sum_p g[p][c] */
+int ubr_channel_sum(int dtype, int64_t npix, int C, const void* g, int64_t g_ps, double* red, void* stream);
+int ubr_cast_f64_to_f32(const double* src, float* dst, int n, double scale, int accumulate, void* stream);
+int ubr_zero(void* p, int64_t bytes, void* stream);
+
+const char* ubr_last_error(void);
+int ubr_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UBRESNET_HIP_H */

@@ -1,0 +1,438 @@
+"""Per-kernel parity tests (GPU): every C-ABI entry point against a plain PyTorch fp32 CPU
+restatement of the same op, on seeded inputs.  Integer outputs bit-exact; fp32 within 2e-5 of
+the output scale (MFMA fp32 is an exact fmaf chain; only summation order differs); bf16/f16
+within 1.2e-2 of the output scale with both sides fed the SAME rounded operands.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from ubresnet_amd import ops
+    from ubresnet_amd.ops import Affine
+
+DEV = "cuda"
+DTS = [torch.float32, torch.bfloat16]
+
+
+def tol(dt):
+    return 2e-5 if dt == torch.float32 else 1.2e-2
+
+
+def rnd(dt, t):
+    """round to the compute type and come back (so both sides see identical operands)"""
+    return t.to(dt).float()
+
+
+def nhwc(t, dt):
+    return t.permute(0, 2, 3, 1).contiguous().to(dt).to(DEV)
+
+
+def nchw(t):
+    return t.float().permute(0, 3, 1, 2).cpu()
+
+
+def close(got, ref, rel, what=""):
+    scale = max(ref.abs().max().item(), 1e-6)
+    err = (got - ref).abs().max().item()
+    assert err <= rel * scale, "%s: max err %.3e vs scale %.3e (rel %.2e > %.2e)" % (what, err, scale, err / scale, rel)
+
+
+def gen(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def lo_zero(n):
+    return torch.zeros(n, device=DEV)
+
+
+CONV_CASES = [
+    # N, H, W, Cin, Cout, k, stride, dil, xf, bias, stats, addend, tile_hint
+    (2, 24, 40, 16, 16, 3, 1, 1, True, False, True, False, 0),
+    (1, 16, 32, 16, 16, 3, 1, 1, False, False, False, False, 1),
+    (1, 16, 32, 16, 16, 3, 1, 1, False, True, True, True, 2),
+    (2, 16, 16, 32, 64, 3, 1, 1, True, False, True, False, 0),
+    (1, 16, 32, 32, 32, 3, 1, 1, False, False, True, False, 3),
+    (1, 16, 32, 64, 64, 3, 1, 1, True, False, True, False, 4),
+    (1, 8, 16, 64, 64, 3, 1, 1, False, False, False, False, 5),
+    (1, 8, 16, 64, 128, 3, 1, 1, False, False, True, False, 6),
+    (1, 8, 16, 32, 32, 3, 1, 1, False, False, False, False, 7),
+    (1, 8, 16, 32, 16, 3, 1, 1, False, False, False, False, 8),
+    (1, 8, 16, 32, 32, 3, 1, 1, False, False, False, False, 9),
+    (1, 8, 16, 32, 16, 3, 1, 1, False, False, True, False, 10),
+    (2, 32, 32, 16, 32, 3, 2, 1, False, False, True, False, 0),
+    (1, 32, 64, 32, 64, 3, 2, 1, True, False, True, False, 0),
+    (2, 16, 32, 16, 32, 1, 1, 1, False, False, True, False, 0),
+    (2, 32, 32, 32, 64, 1, 2, 1, False, False, True, False, 0),
+    (1, 32, 32, 16, 16, 7, 1, 1, False, True, True, False, 0),
+    (1, 16, 24, 128, 16, 3, 1, 3, False, True, True, False, 0),
+    (1, 16, 24, 64, 16, 3, 1, 5, False, True, False, False, 0),
+    (1, 4, 8, 512, 64, 3, 1, 1, False, False, True, False, 0),
+    (1, 12, 20, 48, 32, 3, 1, 1, True, False, True, False, 0),   # ragged: not tile multiples, Cin=48
+]
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_forward(case, dt):
+    N, H, W, Cin, Cout, k, stride, dil, xf, bias, stats, addend, hint = case
+    pad = dil * (k // 2)
+    x = rnd(dt, gen(N, Cin, H, W, seed=1))
+    w = gen(Cout, Cin, k, k, seed=2, scale=(2.0 / (k * k * Cin)) ** 0.5)
+    b = gen(Cout, seed=3) if bias else None
+    xin = x
+    aff = None
+    if xf:
+        sc, sh = gen(Cin, seed=4).abs() + 0.5, gen(Cin, seed=5) * 0.3
+        xin = rnd(dt, F.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)))
+        aff = Affine(sc.to(DEV), sh.to(DEV), lo_zero(Cin))
+    ref = F.conv2d(xin, rnd(dt, w), b, stride, pad, dil)
+    OH, OW = ref.shape[2], ref.shape[3]
+    ad = None
+    if addend:
+        ad = rnd(dt, gen(N, Cout, OH, OW, seed=6))
+        ref = ref + ad
+    # input as a channel slice of a wider buffer, output as a channel slice too
+    xbuf = torch.zeros((N, H, W, Cin + 16), dtype=dt, device=DEV)
+    xbuf[..., 16:] = nhwc(x, dt)
+    ybuf = torch.full((N, OH, OW, Cout + 32), 7.0, dtype=dt, device=DEV)
+    yv = ybuf[..., 32:]
+    wp = ops.pack_weights(w.to(DEV), dt, Cout, Cin, Cin * k * k, k * k, k * k)
+    st = torch.zeros(2 * Cout, dtype=torch.float64, device=DEV) if stats else None
+    ops.conv(xbuf[..., 16:], wp, yv, ops.conv_taps(k, dil, pad), Cout, S=stride, xf=aff,
+             bias=b.to(DEV) if bias else None, addend=nhwc(ad, dt) if addend else None, stats=st, tile_hint=hint)
+    torch.cuda.synchronize()
+    close(nchw(yv), ref, tol(dt), "conv out")
+    assert (ybuf[..., :32].float() == 7.0).all(), "conv wrote outside its channel slice"
+    if stats:
+        s = st.cpu()
+        n = N * OH * OW
+        rs, rss = ref.sum(dim=(0, 2, 3)).double(), (ref.double() ** 2).sum(dim=(0, 2, 3))
+        assert (s[:Cout] - rs).abs().max().item() <= tol(dt) * n * max(ref.abs().max().item(), 1e-6)
+        assert (s[Cout:] - rss).abs().max().item() <= 2 * tol(dt) * rss.max().item() + 1e-6
+
+
+@pytest.mark.parametrize("dt", DTS + [torch.float16])
+def test_deconv_forward_and_grads(dt):
+    """ConvTranspose2d(k4,s2,p1) as 4 phases into a concat slice; its data and weight gradients."""
+    N, H, W, Cin, Cd = 2, 8, 12, 32, 16
+    x = rnd(dt, gen(N, Cin, H, W, seed=1))
+    w = gen(Cin, Cd, 4, 4, seed=2, scale=0.1)
+    xr = x.clone().requires_grad_(True)
+    wr = rnd(dt, w).clone().requires_grad_(True)
+    ref = F.conv_transpose2d(xr, wr, None, 2, 1)
+    cat = torch.zeros((N, 2 * H, 2 * W, Cd + 16), dtype=dt, device=DEV)
+    up = cat[..., :Cd]
+    wp = ops.pack_weights(w.to(DEV), dt, Cd, Cin, 16, Cd * 16, 16)
+    for ry in range(2):
+        for rx in range(2):
+            ops.conv(nhwc(x, dt), wp, up[:, ry::2, rx::2, :], ops.transposed_phase_taps(4, 1, 1, 2, ry, rx), Cd)
+    torch.cuda.synchronize()
+    close(nchw(up), ref.detach(), tol(dt), "deconv fwd")
+    g = rnd(dt, gen(*ref.shape, seed=3))
+    ref.backward(g)
+    gcat = torch.zeros((N, 2 * H, 2 * W, Cd + 16), dtype=dt, device=DEV)
+    gcat[..., :Cd] = nhwc(g, dt)
+    gup = gcat[..., :Cd]
+    # data gradient = stride-2 conv over g
+    wpd = ops.pack_weights(w.to(DEV), dt, Cin, Cd, Cd * 16, 16, 16)
+    gx = torch.empty((N, H, W, Cin), dtype=dt, device=DEV)
+    ops.conv(gup, wpd, gx, ops.conv_taps(4, 1, 1), Cin, S=2)
+    close(nchw(gx), xr.grad, tol(dt), "deconv dgrad")
+    dW = torch.full((Cin, Cd, 4, 4), 5.0, device=DEV)
+    ws = ops.WgradWorkspace()
+    xd = nhwc(x, dt)
+    for ry in range(2):
+        for rx in range(2):
+            ops.wgrad(xd, gup[:, ry::2, rx::2, :], ops.transposed_phase_taps(4, 1, 1, 2, ry, rx), dW, 16, Cd * 16, Cd, Cin, ws)
+    torch.cuda.synchronize()
+    close(dW.cpu(), wr.grad, 2 * tol(dt), "deconv wgrad")
+
+
+GRAD_CASES = [
+    # N, H, W, Cin, Cout, k, stride, xf
+    (2, 24, 40, 16, 16, 3, 1, True),
+    (1, 16, 32, 32, 32, 3, 1, False),
+    (2, 16, 16, 64, 32, 3, 1, True),
+    (2, 32, 32, 16, 32, 3, 2, False),
+    (1, 16, 32, 32, 64, 1, 2, False),
+    (2, 16, 16, 32, 16, 1, 1, False),
+    (1, 24, 24, 16, 16, 7, 1, False),
+    (1, 12, 20, 48, 32, 3, 1, False),
+    (1, 4, 8, 256, 128, 3, 1, False),
+]
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("case", GRAD_CASES)
+def test_conv_dgrad_wgrad(case, dt):
+    N, H, W, Cin, Cout, k, stride, xf = case
+    pad = k // 2
+    x = rnd(dt, gen(N, Cin, H, W, seed=1))
+    w = gen(Cout, Cin, k, k, seed=2, scale=(2.0 / (k * k * Cin)) ** 0.5)
+    aff, xin = None, x
+    if xf:
+        sc, sh = gen(Cin, seed=4).abs() + 0.5, gen(Cin, seed=5) * 0.3
+        xin = rnd(dt, F.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)))
+        aff = Affine(sc.to(DEV), sh.to(DEV), lo_zero(Cin))
+    xr = xin.clone().requires_grad_(True)
+    wr = rnd(dt, w).clone().requires_grad_(True)
+    y = F.conv2d(xr, wr, None, stride, pad)
+    g = rnd(dt, gen(*y.shape, seed=3))
+    y.backward(g)
+    gd = nhwc(g, dt)
+    # ---- weight gradient ----
+    dW = torch.full((Cout, Cin, k, k), 3.0, device=DEV)
+    ops.wgrad(nhwc(x, dt), gd, ops.conv_taps(k, 1, pad), dW, Cin * k * k, k * k, Cout, Cin, ops.WgradWorkspace(), S=stride, xf=aff)
+    torch.cuda.synchronize()
+    close(dW.cpu(), wr.grad, 2 * tol(dt), "wgrad")
+    # accumulate flag
+    ops.wgrad(nhwc(x, dt), gd, ops.conv_taps(k, 1, pad), dW, Cin * k * k, k * k, Cout, Cin, ops.WgradWorkspace(), S=stride, xf=aff, accumulate=True)
+    close(dW.cpu(), 2 * wr.grad, 2 * tol(dt), "wgrad accumulate")
+    # ---- data gradient (w.r.t. the conv input as the conv saw it) ----
+    wpd = ops.pack_weights(w.to(DEV), dt, Cin, Cout, k * k, Cin * k * k, k * k)
+    gx = torch.empty((N, H, W, Cin), dtype=dt, device=DEV)
+    ad = rnd(dt, gen(N, Cin, H, W, seed=9))
+    add = nhwc(ad, dt)
+    if stride == 1:
+        ops.conv(gd, wpd, gx, ops.conv_dgrad_taps_s1(k, 1, pad), Cin, addend=add)
+    else:
+        gx.copy_(add)
+        for ry in range(2):
+            for rx in range(2):
+                taps = ops.transposed_phase_taps(k, 1, pad, 2, ry, rx)
+                if taps:
+                    ops.conv(gd, wpd, gx[:, ry::2, rx::2, :], taps, Cin, addend=gx[:, ry::2, rx::2, :])
+    torch.cuda.synchronize()
+    close(nchw(gx), xr.grad + ad, tol(dt), "dgrad")
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("cfg", [(2, 1, 40, 56, 16), (1, 3, 32, 32, 32), (1, 1, 16, 16, 16)])
+def test_stem(cfg, dt):
+    N, Cin, H, W, Cout = cfg
+    x = gen(N, Cin, H, W, seed=1)
+    x[x.abs() < 1.2] = 0.0           # sparse like LArTPC crops
+    x[0, :, :16, :16] = 0.0          # one all-zero tile -> exercises the skip path
+    w = gen(Cout, Cin, 7, 7, seed=2, scale=0.2)
+    b = gen(Cout, seed=3)
+    ref = F.conv2d(x, w, b, 1, 3)
+    y = torch.empty((N, H, W, Cout), dtype=dt, device=DEV)
+    st = torch.zeros(2 * Cout, dtype=torch.float64, device=DEV)
+    ops.stem_forward(x.to(DEV), w.to(DEV), b.to(DEV), y, st)
+    torch.cuda.synchronize()
+    close(nchw(y), ref, tol(dt), "stem fwd")
+    close(st[:Cout].cpu().float(), ref.sum(dim=(0, 2, 3)), 1e-4, "stem stats sum")
+    close(st[Cout:].cpu().float(), (ref ** 2).sum(dim=(0, 2, 3)), 1e-4, "stem stats sumsq")
+    g = rnd(dt, gen(N, Cout, H, W, seed=4))
+    wr = w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    F.conv2d(x, wr, br, 1, 3).backward(g)
+    dW = torch.empty_like(w, device=DEV)
+    dB = torch.empty(Cout, device=DEV)
+    ops.stem_wgrad(x.to(DEV), nhwc(g, dt), dW, dB, ops.WgradWorkspace())
+    torch.cuda.synchronize()
+    close(dW.cpu(), wr.grad, 1e-4, "stem wgrad")
+    close(dB.cpu(), br.grad, 1e-4, "stem bgrad")
+
+
+def _bn_vectors(C, seed):
+    gamma = gen(C, seed=seed).abs() + 0.5
+    beta = gen(C, seed=seed + 1) * 0.2
+    return gamma, beta
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_bn_finalize(dt):
+    C, n = 32, 5000
+    v = gen(n, C, seed=1) * 2 + 3
+    st = torch.cat([v.double().sum(0), (v.double() ** 2).sum(0)]).to(DEV)
+    gamma, beta = _bn_vectors(C, 2)
+    rm, rv = gen(C, seed=4).to(DEV), (gen(C, seed=5).abs() + 0.5).to(DEV)
+    rm0, rv0 = rm.clone().cpu(), rv.clone().cpu()
+    nbt = torch.zeros((), dtype=torch.int64, device=DEV)
+    out = [torch.empty(C, device=DEV) for _ in range(4)]
+    ops.bn_finalize(st, n, gamma.to(DEV), beta.to(DEV), rm, rv, nbt, 0.1, 1e-5, *out)
+    mean, var = v.mean(0), v.var(0, unbiased=False)
+    invstd = 1 / torch.sqrt(var + 1e-5)
+    close(out[0].cpu(), gamma * invstd, 1e-5, "scale")
+    close(out[1].cpu(), beta - mean * gamma * invstd, 1e-5, "shift")
+    close(out[2].cpu(), mean, 1e-5, "mean")
+    close(out[3].cpu(), invstd, 1e-5, "invstd")
+    close(rm.cpu(), 0.9 * rm0 + 0.1 * mean, 1e-5, "running_mean")
+    close(rv.cpu(), 0.9 * rv0 + 0.1 * v.var(0, unbiased=True), 1e-5, "running_var")
+    assert int(nbt.item()) == 1
+    sc, sh = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    ops.bn_eval_affine(gamma.to(DEV), beta.to(DEV), rm, rv, 1e-5, sc, sh)
+    r_is = 1 / torch.sqrt(rv.cpu() + 1e-5)
+    close(sc.cpu(), gamma * r_is, 1e-5, "eval scale")
+    close(sh.cpu(), beta - rm.cpu() * gamma * r_is, 1e-5, "eval shift")
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("bypass", [False, True])
+@pytest.mark.parametrize("C", [16, 96])
+def test_block_tail(dt, bypass, C):
+    """relu(relu(bn2(c2)) + shortcut) forward and the whole backward (both BatchNorms) vs autograd."""
+    N, H, W = 2, 12, 20
+    c2 = rnd(dt, gen(N, C, H, W, seed=1))
+    sc_in = rnd(dt, gen(N, C, H, W, seed=2))
+    g2, b2 = _bn_vectors(C, 3)
+    gb, bb = _bn_vectors(C, 5)
+    go1, go2 = rnd(dt, gen(N, C, H, W, seed=7)), rnd(dt, gen(N, C, H, W, seed=8))
+    c2r, scr = c2.clone().requires_grad_(True), sc_in.clone().requires_grad_(True)
+    g2r, b2r, gbr, bbr = [t.clone().requires_grad_(True) for t in (g2, b2, gb, bb)]
+    r2 = F.relu(F.batch_norm(c2r, None, None, g2r, b2r, True, 0.1, 1e-5))
+    sh = F.batch_norm(scr, None, None, gbr, bbr, True, 0.1, 1e-5) if bypass else scr
+    out = F.relu(r2 + sh)
+    out.backward(go1 + go2)
+
+    def stats(t):
+        m = t.mean(dim=(0, 2, 3))
+        v = t.var(dim=(0, 2, 3), unbiased=False)
+        return m, 1 / torch.sqrt(v + 1e-5)
+    m2, i2 = stats(c2)
+    mb, ib = stats(sc_in)
+    s2, t2 = (g2 * i2), (b2 - m2 * g2 * i2)
+    sb, tb = (gb * ib), (bb - mb * gb * ib)
+    d = lambda t: t.to(DEV)
+    c2d, scd = nhwc(c2, dt), nhwc(sc_in, dt)
+    outd = torch.empty((N, H, W, C), dtype=dt, device=DEV)
+    ops.block_tail_fwd(c2d, d(s2), d(t2), scd, d(sb) if bypass else None, d(tb) if bypass else None, outd)
+    torch.cuda.synchronize()
+    close(nchw(outd), out.detach(), tol(dt), "tail fwd")
+    red = torch.zeros(4 * C, dtype=torch.float64, device=DEV)
+    go1d, go2d = nhwc(go1, dt), nhwc(go2, dt)
+    ops.block_tail_bwd_reduce(go1d, go2d, outd, c2d, d(s2), d(t2), d(m2), d(i2), scd if bypass else None,
+                              d(mb) if bypass else None, d(ib) if bypass else None, red[:2 * C], red[2 * C:] if bypass else None)
+    k = torch.empty(4 * C, device=DEV)
+    dg2, db2, dgb, dbb = [torch.empty(C, device=DEV) for _ in range(4)]
+    cnt = N * H * W
+    ops.bn_bwd_finalize(red[:2 * C], cnt, C, dg2, db2, False, k[:C], k[C:2 * C])
+    if bypass:
+        ops.bn_bwd_finalize(red[2 * C:], cnt, C, dgb, dbb, False, k[2 * C:3 * C], k[3 * C:])
+    g_c2 = torch.empty((N, H, W, C), dtype=dt, device=DEV)
+    g_sc = torch.empty((N, H, W, C), dtype=dt, device=DEV)
+    ops.block_tail_bwd_apply(go1d, go2d, outd, c2d, d(s2), d(t2), d(m2), d(i2), k[:C], k[C:2 * C],
+                             scd if bypass else None, d(sb) if bypass else None, d(mb) if bypass else None, d(ib) if bypass else None,
+                             k[2 * C:3 * C] if bypass else None, k[3 * C:] if bypass else None, g_c2, g_sc)
+    torch.cuda.synchronize()
+    t = 4 * tol(dt)
+    close(nchw(g_c2), c2r.grad, t, "g_c2")
+    close(nchw(g_sc), scr.grad, t, "g_shortcut")
+    close(dg2.cpu(), g2r.grad, t, "dgamma2")
+    close(db2.cpu(), b2r.grad, t, "dbeta2")
+    if bypass:
+        close(dgb.cpu(), gbr.grad, t, "dgamma_b")
+        close(dbb.cpu(), bbr.grad, t, "dbeta_b")
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("relu", [True, False])
+def test_bn_backward(dt, relu):
+    N, C, H, W = 2, 32, 10, 12
+    c = rnd(dt, gen(N, C, H, W, seed=1))
+    ga, ga2 = rnd(dt, gen(N, C, H, W, seed=2)), rnd(dt, gen(N, C, H, W, seed=3))
+    gm, bt = _bn_vectors(C, 4)
+    cr, gr, br = c.clone().requires_grad_(True), gm.clone().requires_grad_(True), bt.clone().requires_grad_(True)
+    y = F.batch_norm(cr, None, None, gr, br, True, 0.1, 1e-5)
+    a = F.relu(y) if relu else y
+    a.backward(ga + ga2)
+    m = c.mean(dim=(0, 2, 3))
+    istd = 1 / torch.sqrt(c.var(dim=(0, 2, 3), unbiased=False) + 1e-5)
+    sc, sh = gm * istd, bt - m * gm * istd
+    d = lambda t: t.to(DEV)
+    red = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
+    cd, gad, ga2d = nhwc(c, dt), nhwc(ga, dt), nhwc(ga2, dt)
+    ops.bn_bwd_reduce(gad, ga2d, cd, d(sc), d(sh), d(m), d(istd), relu, red)
+    k = torch.empty(2 * C, device=DEV)
+    dg, db = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    ops.bn_bwd_finalize(red, N * H * W, C, dg, db, False, k[:C], k[C:])
+    gc = torch.empty((N, H, W, C), dtype=dt, device=DEV)
+    ops.bn_bwd_apply(gad, ga2d, cd, d(sc), d(sh), d(m), d(istd), relu, k[:C], k[C:], gc)
+    torch.cuda.synchronize()
+    t = 4 * tol(dt)
+    close(nchw(gc), cr.grad, t, "g_c")
+    close(dg.cpu(), gr.grad, t, "dgamma")
+    close(db.cpu(), br.grad, t, "dbeta")
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("stride", [2, 1])
+def test_maxpool(dt, stride):
+    N, C, H, W = 2, 16, 16, 24
+    c = rnd(dt, gen(N, C, H, W, seed=1))
+    sc, sh = gen(C, seed=2).abs() + 0.5, gen(C, seed=3) * 0.3
+    xr = rnd(dt, F.relu(c * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))).requires_grad_(True)
+    p = F.max_pool2d(xr, 3, stride, 1)
+    gp = rnd(dt, gen(*p.shape, seed=4))
+    ge = rnd(dt, gen(N, C, H, W, seed=5))
+    p.backward(gp)
+    aff = Affine(sc.to(DEV), sh.to(DEV), lo_zero(C))
+    cd = nhwc(c, dt)
+    pooled = torch.empty((N, p.shape[2], p.shape[3], C), dtype=dt, device=DEV)
+    cat = torch.zeros((N, H, W, 2 * C), dtype=dt, device=DEV)
+    xcopy = cat[..., C:] if stride == 2 else None
+    ops.maxpool_fwd(cd, aff, pooled, xcopy, stride)
+    torch.cuda.synchronize()
+    close(nchw(pooled), p.detach(), tol(dt), "pool fwd")
+    if stride == 2:
+        close(nchw(cat[..., C:]), xr.detach(), tol(dt), "pool xcopy")
+        assert (cat[..., :C] == 0).all()
+    gx = torch.empty((N, H, W, C), dtype=dt, device=DEV)
+    ops.maxpool_bwd(cd, aff, nhwc(gp, dt), nhwc(ge, dt), gx, stride)
+    torch.cuda.synchronize()
+    # ties between equal maxima only occur at relu zeros, whose gradient the BN/ReLU mask kills
+    # anyway; compare where the input is positive
+    mask = (xr.detach() > 0).float()
+    close(nchw(gx) * mask, (xr.grad + ge) * mask, tol(dt), "pool bwd")
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("C", [3, 4])
+def test_logsoftmax_backward(dt, C):
+    N, H, W = 2, 16, 24
+    z = gen(N, C, H, W, seed=1).requires_grad_(True)
+    lp = F.log_softmax(z, 1)
+    g = gen(N, C, H, W, seed=2)
+    lp.backward(g)
+    out = torch.full((N, H, W, 16), 9.0, dtype=dt, device=DEV)
+    ops.logsoftmax_bwd(g.to(DEV), lp.detach().to(DEV), out)
+    torch.cuda.synchronize()
+    close(nchw(out[..., :C]), z.grad, tol(dt), "logsoftmax bwd")
+    assert (out[..., C:].float() == 0).all()
+
+
+def test_pixelwise_nll_and_confusion():
+    from ubresnet_amd.training.pixelwise_nllloss import PixelWiseNLLLoss
+    from ubresnet_amd import metrics
+    from oracle import uresnet_oracle as O
+    N, C, H, W = 2, 3, 32, 32
+    lp = F.log_softmax(gen(N, C, H, W, seed=1), 1)
+    tg = torch.randint(0, C, (N, H, W), generator=torch.Generator().manual_seed(2))
+    tg[0, :2, :] = -100
+    pw = gen(N, H, W, seed=3).abs() + 0.5
+    lr = lp.clone().requires_grad_(True)
+    ref = O.pixelwise_nll(lr, tg, pw)
+    ref.backward()
+    crit = PixelWiseNLLLoss()
+    ld = lp.to(DEV).requires_grad_(True)
+    loss = crit.forward(ld, tg.to(DEV), pw.to(DEV))
+    loss.backward()
+    assert abs(loss.item() - ref.item()) <= 1e-6 * abs(ref.item())
+    close(ld.grad.cpu(), lr.grad, 1e-6, "nll grad")
+    # class weights
+    cw = torch.tensor([0.5, 2.0, 1.5])
+    ref2 = O.pixelwise_nll(lp, tg, pw, cw)
+    loss2 = PixelWiseNLLLoss(weight=cw)(lp.to(DEV), tg.to(DEV), pw.to(DEV))
+    assert abs(loss2.item() - ref2.item()) <= 1e-6 * abs(ref2.item())
+    # accuracy / confusion: bit-exact integers
+    tg2 = tg.clamp(min=0)
+    cm = metrics.confusion_matrix(lp.to(DEV), tg2.to(DEV)).cpu()
+    assert torch.equal(cm, O.confusion_matrix(lp, tg2))
+    acc, racc = metrics.accuracy(lp.to(DEV), tg2.to(DEV)), O.accuracy(lp, tg2)
+    assert all(abs(a - b) < 1e-9 for a, b in zip(acc, racc))

@@ -1,0 +1,162 @@
+"""Whole-network parity (GPU): UResNet on the HIP path vs (a) the golden fixtures produced by the
+reference's own code and (b) the CPU oracle on the same seeded weights and inputs.
+
+Tolerances (BASELINE.json north_star): fp32 log-probabilities within 1e-3 relative, class-map
+arg-max bit-exact wherever the top-2 margin exceeds the tolerance; gradients within 2e-3 of
+each tensor's scale (fp32, different summation order over up to 8k pixels x 52 BatchNorms).
+bf16: reported/loosely bounded (storage rounding), IoU vs the fp32 class map >= 0.98.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import uresnet_oracle as O
+from ubresnet_amd import synthetic
+
+if torch.cuda.is_available():
+    from ubresnet_amd.models.ub_uresnet import UResNet
+    from ubresnet_amd.training.pixelwise_nllloss import PixelWiseNLLLoss
+    from ubresnet_amd import metrics
+
+torch.set_num_threads(min(16, os.cpu_count() or 1))
+
+
+def _model(sd, num_classes=3, cin=1, ip=16):
+    m = UResNet(num_classes=num_classes, input_channels=cin, inplanes=ip)
+    m.load_state_dict(sd)
+    return m.to("cuda")
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / max(b.abs().max().item(), 1e-12))
+
+
+@pytest.mark.parametrize("tag", ["2x1x64x64", "1x1x96x128"])
+def test_forward_matches_reference_fixture(golden_dir, tag):
+    g = np.load(os.path.join(golden_dir, "uresnet_ip16_%s.npz" % tag))
+    B, C, H, W, seed0, wseed = [int(v) for v in g["meta"]]
+    sd = O.seeded_state_dict(O.uresnet_schema(3, C, 16, 16), wseed)
+    x, lab, wgt = synthetic.make_batch(B, H, W, seed0)
+    m = _model(sd)
+    m.eval()
+    with torch.no_grad():
+        out = m(torch.from_numpy(x).cuda()).cpu()
+    ref = torch.from_numpy(g["logp_eval"])
+    assert _rel(out, ref) <= 1e-3, "eval log-probs rel err %.3e" % _rel(out, ref)
+    top2 = torch.topk(ref, 2, dim=1)[0]
+    safe = (top2[:, 0] - top2[:, 1]) > 2e-3 * ref.abs().max()
+    assert torch.equal(out.argmax(1)[safe], ref.argmax(1)[safe]), "class map differs where the margin is safe"
+    print("eval rel err", tag, _rel(out, ref))
+
+
+@pytest.mark.parametrize("tag", ["2x1x64x64", "1x1x96x128"])
+def test_train_step_matches_reference_fixture_and_oracle(golden_dir, tag):
+    g = np.load(os.path.join(golden_dir, "uresnet_ip16_%s.npz" % tag))
+    B, C, H, W, seed0, wseed = [int(v) for v in g["meta"]]
+    sd = O.seeded_state_dict(O.uresnet_schema(3, C, 16, 16), wseed)
+    x, lab, wgt = synthetic.make_batch(B, H, W, seed0)
+    xt, lt, wt = torch.from_numpy(x), torch.from_numpy(lab), torch.from_numpy(wgt)
+    m = _model(sd)
+    m.train()
+    crit = PixelWiseNLLLoss()
+    out = m.forward(xt.cuda())
+    loss = crit.forward(out, lt.cuda(), wt.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    ref_out = torch.from_numpy(g["logp_train"])
+    e = _rel(out.detach().cpu(), ref_out)
+    assert e <= 1e-3, "train log-probs rel err %.3e" % e
+    assert abs(loss.item() - float(g["loss"])) <= 1e-4 * abs(float(g["loss"]))
+    # running statistics follow nn.BatchNorm2d (momentum 0.1, unbiased variance)
+    after = m.state_dict()
+    for k in ("bn1", "bn10"):
+        assert _rel(after[k + ".running_mean"].cpu(), torch.from_numpy(g[k + "_running_mean"])) <= 1e-4
+        assert _rel(after[k + ".running_var"].cpu(), torch.from_numpy(g[k + "_running_var"])) <= 1e-4
+    assert int(after["bn1.num_batches_tracked"]) == int(g["nbt"])
+    # gradients: fixture norms/samples from the reference, full tensors from the oracle
+    _, ograds, _, _ = O.train_step_grads(O.uresnet_forward, sd, xt, lt, wt)
+    names = [str(n) for n in g["grad_names"]]
+    worst = (0.0, "")
+    params = dict(m.named_parameters())
+    for n, ref_norm in zip(names, g["grad_norms"]):
+        gv = params[n].grad.detach().cpu()
+        og = ograds[n]
+        scale = max(og.abs().max().item(), 1e-10)
+        err = (gv - og).abs().max().item() / scale
+        if err > worst[0]:
+            worst = (err, n)
+        norm = float(gv.double().norm())
+        assert abs(norm - ref_norm) <= 2e-3 * ref_norm + 1e-7, "grad norm %s: %g vs %g" % (n, norm, ref_norm)
+        rs = np.random.RandomState(7)
+        flat = gv.reshape(-1).numpy()
+        idx = np.sort(rs.choice(flat.shape[0], size=min(16, flat.shape[0]), replace=False))
+        assert np.abs(flat[idx] - g["gs__" + n]).max() <= 2e-3 * scale + 1e-8, n
+    print("worst grad rel err", worst)
+    assert worst[0] <= 2e-3, "gradient %s rel err %.3e" % (worst[1], worst[0])
+
+
+def test_four_classes_and_metrics(golden_dir):
+    g = np.load(os.path.join(golden_dir, "uresnet_ip16_nc4_1x1x64x96.npz"))
+    B, C, H, W, seed0, wseed = [int(v) for v in g["meta"]]
+    sd = O.seeded_state_dict(O.uresnet_schema(4, C, 16, 16), wseed)
+    x, lab, _ = synthetic.make_batch(B, H, W, seed0)
+    m = _model(sd, num_classes=4)
+    m.eval()
+    with torch.no_grad():
+        out = m(torch.from_numpy(x).cuda())
+    ref = torch.from_numpy(g["logp_eval"])
+    assert _rel(out.cpu(), ref) <= 1e-3
+    lt = torch.from_numpy(lab)
+    assert torch.equal(metrics.confusion_matrix(out, lt.cuda()).cpu(), O.confusion_matrix(out.cpu(), lt))
+
+
+def test_bf16_tracks_fp32():
+    sd = O.seeded_state_dict(O.uresnet_schema(3, 1, 16, 16), 42)
+    x, lab, wgt = synthetic.make_batch(2, 128, 128, 1000)
+    xt = torch.from_numpy(x).cuda()
+    m = _model(sd)
+    m.eval()
+    with torch.no_grad():
+        ref = m(xt)
+        m.compute_dtype = torch.bfloat16
+        out = m(xt)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            m.compute_dtype = None
+            out2 = m(xt)
+    assert torch.equal(out, out2), "autocast and compute_dtype select the same path"
+    cm = torch.zeros(3, 3, dtype=torch.int64)
+    a, b = ref.argmax(1).cpu().reshape(-1), out.argmax(1).cpu().reshape(-1)
+    cm = torch.bincount(a * 3 + b, minlength=9).reshape(3, 3)
+    iou = O.iou_from_confusion(cm)
+    agree = float((a == b).float().mean())
+    print("bf16 vs fp32: max abs logp diff %.3e, pixel agreement %.5f, IoU %s" % ((out - ref).abs().max().item(), agree, iou))
+    assert agree >= 0.98
+    # bf16 train step runs and produces finite gradients of the right scale
+    m.train()
+    m.compute_dtype = torch.bfloat16
+    crit = PixelWiseNLLLoss()
+    loss = crit(m(xt), torch.from_numpy(lab).cuda(), torch.from_numpy(wgt).cuda())
+    loss.backward()
+    m2 = _model(sd)
+    m2.train()
+    loss2 = crit(m2(xt), torch.from_numpy(lab).cuda(), torch.from_numpy(wgt).cuda())
+    loss2.backward()
+    assert abs(loss.item() - loss2.item()) <= 3e-2 * abs(loss2.item())
+    for (n, p), (_, q) in zip(m.named_parameters(), m2.named_parameters()):
+        assert torch.isfinite(p.grad).all(), n
+        cos = torch.nn.functional.cosine_similarity(p.grad.reshape(1, -1).double(), q.grad.reshape(1, -1).double()).item()
+        assert cos >= 0.9 or q.grad.abs().max() < 1e-6, "bf16 gradient of %s diverges from fp32 (cos %.3f)" % (n, cos)
+
+
+def test_errors_are_exceptions():
+    m = UResNet(num_classes=3, input_channels=1, inplanes=16).cuda()
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 1, 48, 64, device="cuda"))       # not a multiple of 32
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 3, 64, 64, device="cuda"))       # wrong channel count
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 1, 64, 64))                      # CPU tensor: no fallback

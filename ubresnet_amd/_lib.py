@@ -1,0 +1,170 @@
+"""ctypes binding of libubresnet_hip.so (the C ABI in include/ubresnet_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or a call fails, a
+RuntimeError is raised (callers in the reference catch ``Exception`` and break their loop,
+training/train_ubresnet2018_wlarcv2.py:230-239, so errors must be exceptions, never aborts).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libubresnet_hip.so")
+
+F32, BF16, F16 = 0, 1, 2
+MAX_TAPS = 64
+_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
+_CPU = {F32: 4, BF16: 8, F16: 8}
+
+
+def dtype_id(dt: torch.dtype) -> int:
+    try:
+        return _DT[dt]
+    except KeyError:
+        raise RuntimeError("ubresnet_amd: unsupported compute dtype %s" % dt)
+
+
+def chans_per_unit(dt: torch.dtype) -> int:
+    return _CPU[dtype_id(dt)]
+
+
+class Tensor(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("sn", C.c_int64), ("sy", C.c_int64), ("sx", C.c_int64)]
+
+
+class ChanAffine(C.Structure):
+    _fields_ = [("scale", C.c_void_p), ("shift", C.c_void_p), ("lo", C.c_void_p)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int32),
+        ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32),
+        ("x", Tensor),
+        ("xf", ChanAffine),
+        ("w", C.c_void_p),
+        ("Cout", C.c_int32), ("Cout_pad", C.c_int32),
+        ("ntaps", C.c_int32),
+        ("dy", C.c_int8 * MAX_TAPS), ("dx", C.c_int8 * MAX_TAPS),
+        ("wt", C.c_uint8 * MAX_TAPS),
+        ("S", C.c_int32), ("iy0", C.c_int32), ("ix0", C.c_int32),
+        ("OH", C.c_int32), ("OW", C.c_int32),
+        ("y", Tensor),
+        ("addend", Tensor),
+        ("bias", C.c_void_p),
+        ("stats", C.c_void_p),
+        ("epilogue", C.c_int32),
+        ("tile_hint", C.c_int32),
+    ]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int32),
+        ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32),
+        ("x", Tensor),
+        ("xf", ChanAffine),
+        ("GH", C.c_int32), ("GW", C.c_int32), ("Cout", C.c_int32),
+        ("g", Tensor),
+        ("ntaps", C.c_int32),
+        ("dy", C.c_int8 * MAX_TAPS), ("dx", C.c_int8 * MAX_TAPS),
+        ("S", C.c_int32), ("iy0", C.c_int32), ("ix0", C.c_int32),
+        ("slabs", C.c_void_p),
+        ("nsplit", C.c_int32),
+    ]
+
+
+# every symbol include/ubresnet_hip.h declares (tests check that all of them are exported)
+SYMBOLS = [
+    "ubr_conv", "ubr_pack_weights", "ubr_wgrad_plan", "ubr_wgrad", "ubr_wgrad_reduce",
+    "ubr_stem_forward", "ubr_stem_wgrad", "ubr_stem_wgrad_workspace",
+    "ubr_bn_finalize", "ubr_bn_eval_affine", "ubr_bn_bwd_reduce", "ubr_bn_bwd_finalize", "ubr_bn_bwd_apply",
+    "ubr_block_tail_fwd", "ubr_block_tail_bwd_reduce", "ubr_block_tail_bwd_apply",
+    "ubr_maxpool_fwd", "ubr_maxpool_bwd",
+    "ubr_logsoftmax_bwd", "ubr_pixelwise_nll_fwd", "ubr_pixelwise_nll_bwd", "ubr_confusion",
+    "ubr_channel_sum", "ubr_cast_f64_to_f32", "ubr_zero", "ubr_last_error", "ubr_version",
+]
+
+_lib = None
+_lock = threading.Lock()
+vp, i32, i64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
+
+
+def _declare(lib):
+    lib.ubr_last_error.restype = C.c_char_p
+    lib.ubr_version.restype = C.c_int
+    lib.ubr_stem_wgrad_workspace.restype = C.c_int64
+    lib.ubr_stem_wgrad_workspace.argtypes = [i32] * 5
+    lib.ubr_conv.argtypes = [C.POINTER(ConvDesc), vp]
+    lib.ubr_pack_weights.argtypes = [i32, vp, vp, i32, i32, i32, i32, i64, i64, i32, C.POINTER(C.c_int32), vp]
+    lib.ubr_wgrad_plan.argtypes = [C.POINTER(WgradDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
+    lib.ubr_wgrad.argtypes = [C.POINTER(WgradDesc), vp]
+    lib.ubr_wgrad_reduce.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, i64, i64, C.POINTER(C.c_int32), i32, vp]
+    lib.ubr_stem_forward.argtypes = [i32, vp, i32, i32, i32, i32, vp, vp, i32, Tensor, vp, vp]
+    lib.ubr_stem_wgrad.argtypes = [i32, vp, i32, i32, i32, i32, Tensor, i32, vp, i64, vp, vp, i32, vp]
+    lib.ubr_bn_finalize.argtypes = [vp, f64, vp, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp]
+    lib.ubr_bn_eval_affine.argtypes = [vp, vp, vp, vp, f32, i32, vp, vp, vp]
+    lib.ubr_bn_bwd_reduce.argtypes = [i32, i64, i32, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i32, vp, vp]
+    lib.ubr_bn_bwd_finalize.argtypes = [vp, f64, vp, vp, i32, vp, vp, i32, vp, vp, vp]
+    lib.ubr_bn_bwd_apply.argtypes = [i32, i64, i32, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i32, vp, vp, vp, i64, vp]
+    lib.ubr_block_tail_fwd.argtypes = [i32, i64, i32, vp, i64, vp, vp, vp, i64, vp, vp, vp, i64, vp]
+    lib.ubr_block_tail_bwd_reduce.argtypes = [i32, i64, i32, vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp,
+                                              vp, i64, vp, vp, vp, vp, vp]
+    lib.ubr_block_tail_bwd_apply.argtypes = [i32, i64, i32, vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp,
+                                             vp, i64, vp, vp, vp, vp, vp, vp, i64, vp, i64, vp]
+    lib.ubr_maxpool_fwd.argtypes = [i32, i32, i32, i32, i32, i32, vp, i64, ChanAffine, vp, i64, vp, i64, vp]
+    lib.ubr_maxpool_bwd.argtypes = [i32, i32, i32, i32, i32, i32, vp, i64, ChanAffine, vp, i64, vp, i64, vp, i64, vp]
+    lib.ubr_logsoftmax_bwd.argtypes = [i32, i32, i32, i32, i32, vp, vp, vp, i64, vp]
+    lib.ubr_pixelwise_nll_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i64, vp, vp]
+    lib.ubr_pixelwise_nll_bwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i64, vp, vp]
+    lib.ubr_confusion.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
+    lib.ubr_channel_sum.argtypes = [i32, i64, i32, vp, i64, vp, vp]
+    lib.ubr_cast_f64_to_f32.argtypes = [vp, vp, i32, f64, i32, vp]
+    lib.ubr_zero.argtypes = [vp, i64, vp]
+    for name in SYMBOLS:
+        fn = getattr(lib, name)
+        if name not in ("ubr_last_error", "ubr_version", "ubr_stem_wgrad_workspace"):
+            fn.restype = C.c_int
+
+
+def lib():
+    """Load (once) and return the C-ABI library; raises RuntimeError if it is not built."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise RuntimeError(
+                        "ubresnet_amd: HIP extension %s is missing; build it with "
+                        "`python -m ubresnet_amd.build` (hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+                try:
+                    l = C.CDLL(LIB_PATH)
+                except OSError as e:
+                    raise RuntimeError("ubresnet_amd: cannot load %s: %s" % (LIB_PATH, e))
+                _declare(l)
+                _lib = l
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().ubr_last_error().decode("utf-8", "replace")
+        raise RuntimeError("ubresnet_amd HIP call failed (%d) %s: %s" % (rc, what, msg))
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise RuntimeError("ubresnet_amd: %s must live on a ROCm device (got %s); the HIP path has no CPU fallback"
+                           % (what, t.device))
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()

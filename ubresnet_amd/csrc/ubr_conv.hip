@@ -1,0 +1,483 @@
+// Implicit-GEMM direct convolution on MFMA for NHWC activations (gfx950).
+//
+// Replaces, for the U-ResNet path, every nn.Conv2d / nn.ConvTranspose2d forward and their data
+// gradients (reference: models/common_layers.py:13-15,33,125; models/ub_uresnet.py:60,64;
+// models/ASPP_ResNet.py:199-220,275).  No im2col: a workgroup stages the input halo of its
+// output tile in LDS ONCE (applying the producer's BatchNorm+ReLU as a per-channel affine on the
+// way in and zero-filling the padding), stages the weight slab for its output channels, and every
+// tap reads shifted windows of that same LDS image.
+//
+// GEMM orientation: D[cout][pixel] = W[cout][k] * X[k][pixel], k = (tap, cin) in 16-byte units.
+// The accumulator then holds 4 consecutive output channels of one pixel per lane, so the NHWC
+// store is a packed 8/16-byte store and 16 lanes cover 16 consecutive pixels.
+//
+// Workgroup = 256 threads = 4 waves.  Tile = TH x TW output pixels (TW = 16*TWF) x TN = 16*NT
+// output channels.  Wave w owns FW pixel fragments (16 px each) x NT channel fragments.
+#include "ubr_common.h"
+#include "ubr_host.h"
+
+namespace {
+
+struct ConvK {
+  const char* x; long x_sn, x_sy, x_sx;        // byte strides
+  const float *in_scale, *in_shift, *in_lo;
+  const char* w;
+  char* y; long y_sn, y_sy, y_sx;
+  const char* ad; long a_sn, a_sy, a_sx;
+  const float* bias;
+  double* stats;
+  int H, W;
+  int CU, UPB, lgUPB, nblk;                     // cin units total, per block, log2, number of blocks
+  int Cout, Cout_pad;
+  int ntaps, S, iy0, ix0, OH, OW;
+  int dymin, dxmin, HH, HW;
+  int tiles_x, tiles_y;
+  int nunits, steps;
+  int pixb;                                      // LDS bytes per halo pixel
+  unsigned rw, rw_magic;                         // items per halo row and ceil(2^32/rw)
+  int wl_off, halo_off, red_off;                 // LDS carve offsets
+  int epilogue;
+  int8_t dy[UBR_MAX_TAPS], dx[UBR_MAX_TAPS];
+  uint8_t wt[UBR_MAX_TAPS];
+};
+
+template <typename T> __device__ __forceinline__ void store4(char* p, const float* v);
+template <> __device__ __forceinline__ void store4<float>(char* p, const float* v) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ __forceinline__ void store4<bf16_t>(char* p, const float* v) {
+  *reinterpret_cast<uint2*>(p) = make_uint2(ET<bf16_t>::pk2(v[0], v[1]), ET<bf16_t>::pk2(v[2], v[3]));
+}
+template <> __device__ __forceinline__ void store4<f16_t>(char* p, const float* v) {
+  f16x4_t h; h[0] = (_Float16)v[0]; h[1] = (_Float16)v[1]; h[2] = (_Float16)v[2]; h[3] = (_Float16)v[3];
+  *reinterpret_cast<uint2*>(p) = __builtin_bit_cast(uint2, h);
+}
+template <typename T> __device__ __forceinline__ void load4(const char* p, float* v);
+template <> __device__ __forceinline__ void load4<float>(const char* p, float* v) {
+  float4 f = *reinterpret_cast<const float4*>(p); v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+}
+template <> __device__ __forceinline__ void load4<bf16_t>(const char* p, float* v) {
+  uint2 u = *reinterpret_cast<const uint2*>(p);
+  v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+  v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+}
+template <> __device__ __forceinline__ void load4<f16_t>(const char* p, float* v) {
+  f16x4_t h = __builtin_bit_cast(f16x4_t, *reinterpret_cast<const uint2*>(p));
+  v[0] = (float)h[0]; v[1] = (float)h[1]; v[2] = (float)h[2]; v[3] = (float)h[3];
+}
+
+template <typename T, int FW, int NT, int TWF>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK k) {
+  constexpr int TN = NT * 16;
+  constexpr int F = 4 * FW;
+  constexpr int TH = F / TWF;
+  constexpr int TW = TWF * 16;
+  constexpr int CPU = ET<T>::CPU;
+  constexpr int ESZ = 16 / CPU;
+  static_assert(F % TWF == 0, "tile shape");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* tbl = reinterpret_cast<int*>(smem);
+  char* wl = smem + k.wl_off;
+  char* halo = smem + k.halo_off;
+  float* red = reinterpret_cast<float*>(smem + k.red_off);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, l16 = lane & 15;
+  int t = blockIdx.x;
+  const int tx = t % k.tiles_x; t /= k.tiles_x;
+  const int ty = t % k.tiles_y;
+  const int n = t / k.tiles_y;
+  const int n0 = blockIdx.y * TN;
+  const int oy0 = ty * TH, ox0 = tx * TW;
+  const int hy0 = oy0 * k.S + k.iy0 + k.dymin, hx0 = ox0 * k.S + k.ix0 + k.dxmin;
+
+  for (int u = tid; u < 4 * k.steps; u += 256) {
+    int off = 0;
+    if (u < k.nunits) {
+      const int tap = u >> k.lgUPB, c = u & (k.UPB - 1);
+      off = ((k.dy[tap] - k.dymin) * k.HW + (k.dx[tap] - k.dxmin)) * k.pixb + c * 16;
+    }
+    tbl[u] = off;
+  }
+
+  f32x4 acc[FW][NT];
+#pragma unroll
+  for (int i = 0; i < FW; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int fragbase[FW];
+#pragma unroll
+  for (int i = 0; i < FW; ++i) {
+    const int f = wave * FW + i;
+    const int fr = f / TWF, fc = f % TWF;
+    fragbase[i] = ((fr * k.S) * k.HW + fc * 16 * k.S) * k.pixb + l16 * k.S * k.pixb;
+  }
+
+  const char* xn = k.x + (long)n * k.x_sn;
+  const int nitems = k.HH * (int)k.rw;
+  const bool has_xf = k.in_scale != nullptr;
+
+  for (int blk = 0; blk < k.nblk; ++blk) {
+    if (blk) __syncthreads();
+    // ---- stage the input halo (transform + zero padding) ----
+    for (int i = tid; i < nitems; i += 256) {
+      const int hy = (int)__umulhi((unsigned)i, k.rw_magic);
+      const int rem = i - hy * (int)k.rw;
+      const int hx = rem >> k.lgUPB, c = rem & (k.UPB - 1);
+      const int iy = hy0 + hy, ix = hx0 + hx;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if ((unsigned)iy < (unsigned)k.H && (unsigned)ix < (unsigned)k.W) {
+        const int ch0 = (blk * k.UPB + c) * CPU;
+        v = ldg16(xn + (long)iy * k.x_sy + (long)ix * k.x_sx + (long)ch0 * ESZ);
+        if (has_xf) {
+          float f[CPU];
+          ET<T>::unpack(v, f);
+#pragma unroll
+          for (int e = 0; e < CPU; ++e)
+            f[e] = fmaxf(fmaf(f[e], k.in_scale[ch0 + e], k.in_shift[ch0 + e]), k.in_lo[ch0 + e]);
+          v = ET<T>::pack(f);
+        }
+      }
+      *reinterpret_cast<uint4*>(halo + (hy * k.HW + hx) * k.pixb + c * 16) = v;
+    }
+    // ---- stage the weight slab: [unit][TN][16 B], zero beyond nunits ----
+    for (int i = tid; i < 4 * k.steps * TN; i += 256) {
+      const int u = i / TN, nn = i % TN;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (u < k.nunits) {
+        const int tap = u >> k.lgUPB, c = u & (k.UPB - 1);
+        v = ldg16(k.w + ((long)((int)k.wt[tap] * k.CU + blk * k.UPB + c) * k.Cout_pad + n0 + nn) * 16);
+      }
+      *reinterpret_cast<uint4*>(wl + (long)i * 16) = v;
+    }
+    __syncthreads();
+    // ---- MFMA over (tap, cin-unit) ----
+    for (int s = 0; s < k.steps; ++s) {
+      const int off = tbl[4 * s + q];
+      uint4 wf[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        wf[j] = *reinterpret_cast<const uint4*>(wl + (((4 * s + q) * TN) + j * 16 + l16) * 16);
+#pragma unroll
+      for (int i = 0; i < FW; ++i) {
+        const uint4 a = *reinterpret_cast<const uint4*>(halo + fragbase[i] + off);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = mma_step<T>(acc[i][j], wf[j], a);
+      }
+    }
+  }
+
+  // ---------------------------------- epilogue ----------------------------------
+  float bs[NT][4];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ch = n0 + j * 16 + 4 * q + r;
+      bs[j][r] = (k.bias != nullptr && ch < k.Cout) ? k.bias[ch] : 0.f;
+    }
+  float s1[NT][4], s2[NT][4];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s1[j][r] = 0.f; s2[j][r] = 0.f; }
+
+#pragma unroll
+  for (int i = 0; i < FW; ++i) {
+    const int f = wave * FW + i;
+    const int oy = oy0 + f / TWF, ox = ox0 + (f % TWF) * 16 + l16;
+    const bool valid = (oy < k.OH) && (ox < k.OW);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int ch = n0 + j * 16 + 4 * q;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bs[j][r];
+      if (k.ad != nullptr && valid && ch < k.Cout) {
+        float a4[4];
+        load4<T>(k.ad + (long)n * k.a_sn + (long)oy * k.a_sy + (long)ox * k.a_sx + (long)ch * ESZ, a4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += a4[r];
+      }
+      if (k.stats != nullptr && valid) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[j][r] += v[r]; s2[j][r] += v[r] * v[r]; }
+      }
+      if (k.epilogue == 0) {
+        if (valid && ch < k.Cout)
+          store4<T>(k.y + (long)n * k.y_sn + (long)oy * k.y_sy + (long)ox * k.y_sx + (long)ch * ESZ, v);
+      } else if (j == 0) {
+        // fused LogSoftmax over the first Cout (<=16) channels, fp32 NCHW output
+        float m = -3.0e38f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (ch + r < k.Cout) m = fmaxf(m, v[r]);
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float e = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (ch + r < k.Cout) e += expf(v[r] - m);
+        e += __shfl_xor(e, 16, 64);
+        e += __shfl_xor(e, 32, 64);
+        const float lse = m + logf(e);
+        if (valid) {
+          float* o = reinterpret_cast<float*>(k.y);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (ch + r < k.Cout) o[(((long)n * k.Cout + ch + r) * k.OH + oy) * k.OW + ox] = v[r] - lse;
+        }
+      }
+    }
+  }
+
+  if (k.stats != nullptr) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float a = wave_quadrow_sum16(s1[j][r]);
+        const float b = wave_quadrow_sum16(s2[j][r]);
+        if (l16 == 0) {
+          red[(wave * TN + j * 16 + 4 * q + r) * 2 + 0] = a;
+          red[(wave * TN + j * 16 + 4 * q + r) * 2 + 1] = b;
+        }
+      }
+    __syncthreads();
+    if (tid < TN) {
+      const int ch = n0 + tid;
+      if (ch < k.Cout) {
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { a += (double)red[(w * TN + tid) * 2]; b += (double)red[(w * TN + tid) * 2 + 1]; }
+        atomicAdd(&k.stats[ch], a);
+        atomicAdd(&k.stats[k.Cout + ch], b);
+      }
+    }
+  }
+}
+
+struct TileCfg { int FW, NT, TWF; };
+// id -> config; keep in sync with the dispatch switch
+static const TileCfg kCfgs[] = {
+    {8, 1, 2},  // 0: 16x32 px, 16 ch   (thin, full resolution)
+    {4, 1, 2},  // 1:  8x32 px, 16 ch   (7x7 head: smaller halo)
+    {4, 2, 2},  // 2:  8x32 px, 32 ch
+    {4, 4, 2},  // 3:  8x32 px, 64 ch
+    {2, 4, 1},  // 4:  8x16 px, 64 ch
+    {1, 4, 1},  // 5:  4x16 px, 64 ch
+    {2, 2, 1},  // 6:  8x16 px, 32 ch
+    {2, 1, 1},  // 7:  8x16 px, 16 ch
+    {1, 2, 1},  // 8:  4x16 px, 32 ch
+    {1, 1, 1},  // 9:  4x16 px, 16 ch
+};
+constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
+
+template <typename T, int FW, int NT, int TWF>
+int launch_cfg(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
+  auto fn = conv_igemm_kernel<T, FW, NT, TWF>;
+  if (lds > 64 * 1024) {
+    static thread_local size_t maxset = 0;  // per instantiation
+    if (lds > maxset) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) { ubr_set_error("ubr_conv: cannot raise LDS limit to %zu: %s", lds, hipGetErrorString(e)); return UBR_ELAUNCH; }
+      maxset = lds;
+    }
+  }
+  hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, k);
+  UBR_LAUNCH_CHECK("ubr_conv");
+  return UBR_OK;
+}
+
+template <typename T>
+int launch_T(int cfg, const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
+  switch (cfg) {
+    case 0: return launch_cfg<T, 8, 1, 2>(k, grid, lds, st);
+    case 1: return launch_cfg<T, 4, 1, 2>(k, grid, lds, st);
+    case 2: return launch_cfg<T, 4, 2, 2>(k, grid, lds, st);
+    case 3: return launch_cfg<T, 4, 4, 2>(k, grid, lds, st);
+    case 4: return launch_cfg<T, 2, 4, 1>(k, grid, lds, st);
+    case 5: return launch_cfg<T, 1, 4, 1>(k, grid, lds, st);
+    case 6: return launch_cfg<T, 2, 2, 1>(k, grid, lds, st);
+    case 7: return launch_cfg<T, 2, 1, 1>(k, grid, lds, st);
+    case 8: return launch_cfg<T, 1, 2, 1>(k, grid, lds, st);
+    case 9: return launch_cfg<T, 1, 1, 1>(k, grid, lds, st);
+  }
+  ubr_set_error("ubr_conv: bad tile config %d", cfg);
+  return UBR_EINVAL;
+}
+
+struct Plan { int cfg; size_t lds; int UPB, steps, HH, HW, pixb, wl_off, halo_off, red_off, tiles_x, tiles_y; };
+
+static bool plan_for(const ubr_conv_desc* d, int cfg, int dymin, int dymax, int dxmin, int dxmax, Plan* p) {
+  const TileCfg& c = kCfgs[cfg];
+  const int TN = c.NT * 16, TH = 4 * c.FW / c.TWF, TW = c.TWF * 16;
+  if (d->Cout_pad % TN) return false;
+  if (d->epilogue == 1 && c.NT != 1) return false;
+  const int cpu = ubr_cpu(d->dtype);
+  const int CU = d->Cin / cpu;
+  int UPB = (CU % 4 == 0) ? 4 : (CU % 2 == 0 ? 2 : 1);
+  const int nunits = d->ntaps * UPB;
+  const int steps = (nunits + 3) / 4;
+  const int HH = (TH - 1) * d->S + 1 + (dymax - dymin);
+  const int HW = (TW - 1) * d->S + 1 + (dxmax - dxmin);
+  const int pixb = UPB * 16 + 16;
+  size_t off = ((size_t)16 * steps + 15) & ~(size_t)15;
+  p->wl_off = (int)off; off += (size_t)4 * steps * TN * 16;
+  p->halo_off = (int)off; off += (size_t)HH * HW * pixb;
+  off = (off + 15) & ~(size_t)15;
+  p->red_off = (int)off; off += (size_t)4 * TN * 2 * sizeof(float);
+  p->cfg = cfg; p->lds = off; p->UPB = UPB; p->steps = steps; p->HH = HH; p->HW = HW; p->pixb = pixb;
+  p->tiles_x = ubr_cdiv(d->OW, TW); p->tiles_y = ubr_cdiv(d->OH, TH);
+  if ((size_t)HH * HW * UPB >= 60000) return false;   // exact-division bound of the magic multiply
+  return off <= 160 * 1024;
+}
+
+}  // namespace
+
+extern "C" int ubr_conv(const ubr_conv_desc* d, void* stream) {
+  UBR_CHECK(d != nullptr, "ubr_conv: null descriptor");
+  UBR_CHECK(ubr_dtype_ok(d->dtype), "ubr_conv: bad dtype %d", d->dtype);
+  const int cpu = ubr_cpu(d->dtype), esz = ubr_esize(d->dtype);
+  UBR_CHECK(d->N > 0 && d->H > 0 && d->W > 0 && d->OH > 0 && d->OW > 0, "ubr_conv: empty extent");
+  UBR_CHECK(d->Cin > 0 && d->Cin % cpu == 0, "ubr_conv: Cin=%d must be a positive multiple of %d", d->Cin, cpu);
+  UBR_CHECK(d->Cout > 0 && d->Cout_pad % 16 == 0 && d->Cout <= d->Cout_pad && d->Cout_pad - d->Cout < 16,
+            "ubr_conv: bad Cout=%d Cout_pad=%d", d->Cout, d->Cout_pad);
+  UBR_CHECK(d->ntaps >= 1 && d->ntaps <= UBR_MAX_TAPS, "ubr_conv: ntaps=%d out of range", d->ntaps);
+  UBR_CHECK(d->S == 1 || d->S == 2, "ubr_conv: S=%d unsupported", d->S);
+  UBR_CHECK(d->x.p && d->w && d->y.p, "ubr_conv: null tensor");
+  UBR_CHECK(ubr_aligned16(d->x.p) && ubr_aligned16(d->w), "ubr_conv: x/w must be 16-byte aligned");
+  UBR_CHECK((d->x.sx * esz) % 16 == 0 && (d->x.sy * esz) % 16 == 0 && (d->x.sn * esz) % 16 == 0,
+            "ubr_conv: input strides must keep 16-byte alignment");
+  UBR_CHECK(d->x.sx >= d->Cin, "ubr_conv: x pixel stride %ld < Cin %d", (long)d->x.sx, d->Cin);
+  const bool xf = d->xf.scale != nullptr;
+  UBR_CHECK(xf == (d->xf.shift != nullptr) && xf == (d->xf.lo != nullptr), "ubr_conv: xf needs scale, shift and lo together");
+  if (d->epilogue == 0) {
+    UBR_CHECK(d->Cout % 4 == 0, "ubr_conv: NHWC store needs Cout %% 4 == 0 (got %d)", d->Cout);
+    UBR_CHECK((((uintptr_t)d->y.p) % (4 * esz)) == 0 && d->y.sx % 4 == 0 && d->y.sy % 4 == 0 && d->y.sn % 4 == 0,
+              "ubr_conv: output view must be aligned to 4 elements");
+    UBR_CHECK(d->y.sx >= d->Cout, "ubr_conv: y pixel stride %ld < Cout %d", (long)d->y.sx, d->Cout);
+    if (d->addend.p)
+      UBR_CHECK((((uintptr_t)d->addend.p) % (4 * esz)) == 0 && d->addend.sx % 4 == 0 && d->addend.sy % 4 == 0 && d->addend.sn % 4 == 0,
+                "ubr_conv: addend view must be aligned to 4 elements");
+  } else {
+    UBR_CHECK(d->epilogue == 1 && d->Cout <= 16 && d->Cout_pad == 16, "ubr_conv: log-softmax epilogue needs Cout<=16");
+    UBR_CHECK(d->addend.p == nullptr && d->stats == nullptr, "ubr_conv: log-softmax epilogue takes no addend/stats");
+  }
+  int dymin = 127, dymax = -128, dxmin = 127, dxmax = -128;
+  for (int t = 0; t < d->ntaps; ++t) {
+    dymin = d->dy[t] < dymin ? d->dy[t] : dymin; dymax = d->dy[t] > dymax ? d->dy[t] : dymax;
+    dxmin = d->dx[t] < dxmin ? d->dx[t] : dxmin; dxmax = d->dx[t] > dxmax ? d->dx[t] : dxmax;
+  }
+  UBR_CHECK(dymax - dymin <= 16 && dxmax - dxmin <= 16, "ubr_conv: tap extent too large");
+
+  // ---- choose a tile configuration ----
+  Plan best{}; bool have = false;
+  if (d->tile_hint > 0) {
+    UBR_CHECK(d->tile_hint <= kNumCfgs, "ubr_conv: tile_hint %d out of range", d->tile_hint);
+    have = plan_for(d, d->tile_hint - 1, dymin, dymax, dxmin, dxmax, &best);
+    UBR_CHECK(have, "ubr_conv: tile_hint %d does not fit this shape", d->tile_hint);
+  } else {
+    // widest channel tile that divides Cout_pad; then the largest pixel tile that still yields
+    // >= 512 workgroups (2 per CU), else the smallest tile.
+    const int order_by_nt[3][4] = {{3, 4, 5, -1}, {2, 6, 8, -1}, {0, 1, 7, 9}};
+    for (int g = 0; g < 3 && !have; ++g) {
+      Plan cand{}; bool any = false;
+      for (int i = 0; i < 4; ++i) {
+        const int cfg = order_by_nt[g][i];
+        if (cfg < 0) continue;
+        Plan p{};
+        if (!plan_for(d, cfg, dymin, dymax, dxmin, dxmax, &p)) continue;
+        const TileCfg& c = kCfgs[cfg];
+        if (c.TWF == 2 && d->OW < 32) continue;
+        const long wgs = (long)p.tiles_x * p.tiles_y * d->N * (d->Cout_pad / (c.NT * 16));
+        cand = p; any = true;
+        if (wgs >= 512 && p.lds <= 80 * 1024) break;
+      }
+      if (any) { best = cand; have = true; }
+    }
+    UBR_CHECK(have, "ubr_conv: no tile configuration fits (Cout_pad=%d ntaps=%d)", d->Cout_pad, d->ntaps);
+  }
+
+  ConvK k{};
+  k.x = (const char*)d->x.p; k.x_sn = d->x.sn * esz; k.x_sy = d->x.sy * esz; k.x_sx = d->x.sx * esz;
+  k.in_scale = d->xf.scale; k.in_shift = d->xf.shift; k.in_lo = d->xf.lo;
+  k.w = (const char*)d->w;
+  k.y = (char*)d->y.p; k.y_sn = d->y.sn * esz; k.y_sy = d->y.sy * esz; k.y_sx = d->y.sx * esz;
+  k.ad = (const char*)d->addend.p; k.a_sn = d->addend.sn * esz; k.a_sy = d->addend.sy * esz; k.a_sx = d->addend.sx * esz;
+  k.bias = d->bias; k.stats = d->stats;
+  k.H = d->H; k.W = d->W;
+  k.CU = d->Cin / cpu; k.UPB = best.UPB; k.lgUPB = ubr_ilog2(best.UPB); k.nblk = k.CU / best.UPB;
+  k.Cout = d->Cout; k.Cout_pad = d->Cout_pad;
+  k.ntaps = d->ntaps; k.S = d->S; k.iy0 = d->iy0; k.ix0 = d->ix0; k.OH = d->OH; k.OW = d->OW;
+  k.dymin = dymin; k.dxmin = dxmin; k.HH = best.HH; k.HW = best.HW;
+  k.tiles_x = best.tiles_x; k.tiles_y = best.tiles_y;
+  k.nunits = d->ntaps * best.UPB; k.steps = best.steps; k.pixb = best.pixb;
+  k.rw = (unsigned)(best.HW * best.UPB);
+  k.rw_magic = (unsigned)((0x100000000ull + k.rw - 1) / k.rw);
+  k.wl_off = best.wl_off; k.halo_off = best.halo_off; k.red_off = best.red_off;
+  k.epilogue = d->epilogue;
+  for (int t = 0; t < d->ntaps; ++t) { k.dy[t] = d->dy[t]; k.dx[t] = d->dx[t]; k.wt[t] = d->wt[t]; }
+
+  const TileCfg& c = kCfgs[best.cfg];
+  dim3 grid((unsigned)(best.tiles_x * best.tiles_y * d->N), (unsigned)(d->Cout_pad / (c.NT * 16)));
+  hipStream_t st = (hipStream_t)stream;
+  switch (d->dtype) {
+    case UBR_F32: return launch_T<float>(best.cfg, k, grid, best.lds, st);
+    case UBR_BF16: return launch_T<bf16_t>(best.cfg, k, grid, best.lds, st);
+    default: return launch_T<f16_t>(best.cfg, k, grid, best.lds, st);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight packing
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct PackK {
+  const float* src; char* dst;
+  int M, Mpad, Kvalid, KU, ntaps;
+  long sm, sk;
+  int tapidx[UBR_MAX_TAPS];
+};
+template <typename T>
+__global__ __launch_bounds__(256) void pack_kernel(const PackK k) {
+  constexpr int CPU = ET<T>::CPU;
+  const long total = (long)k.ntaps * k.KU * k.Mpad;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int m = (int)(i % k.Mpad);
+    long r = i / k.Mpad;
+    const int ku = (int)(r % k.KU);
+    const int t = (int)(r / k.KU);
+    float f[CPU];
+#pragma unroll
+    for (int e = 0; e < CPU; ++e) {
+      const int kc = ku * CPU + e;
+      f[e] = (m < k.M && kc < k.Kvalid) ? k.src[(long)m * k.sm + (long)kc * k.sk + k.tapidx[t]] : 0.f;
+    }
+    *reinterpret_cast<uint4*>(k.dst + i * 16) = ET<T>::pack(f);
+  }
+}
+}  // namespace
+
+extern "C" int ubr_pack_weights(int dtype, const float* src, void* dst, int M, int Mpad, int Kvalid, int Kpad,
+                                int64_t sm, int64_t sk, int ntaps, const int32_t* tapidx_host, void* stream) {
+  UBR_CHECK(ubr_dtype_ok(dtype), "ubr_pack_weights: bad dtype");
+  const int cpu = ubr_cpu(dtype);
+  UBR_CHECK(src && dst && tapidx_host, "ubr_pack_weights: null pointer");
+  UBR_CHECK(M > 0 && Mpad >= M && Mpad % 16 == 0 && Kvalid > 0 && Kpad >= Kvalid && Kpad % cpu == 0,
+            "ubr_pack_weights: bad extents M=%d Mpad=%d K=%d Kpad=%d", M, Mpad, Kvalid, Kpad);
+  UBR_CHECK(ntaps >= 1 && ntaps <= UBR_MAX_TAPS, "ubr_pack_weights: ntaps out of range");
+  UBR_CHECK(ubr_aligned16(dst), "ubr_pack_weights: dst must be 16-byte aligned");
+  PackK k{};
+  k.src = src; k.dst = (char*)dst; k.M = M; k.Mpad = Mpad; k.Kvalid = Kvalid; k.KU = Kpad / cpu; k.ntaps = ntaps;
+  k.sm = sm; k.sk = sk;
+  for (int t = 0; t < ntaps; ++t) k.tapidx[t] = tapidx_host[t];
+  const long total = (long)ntaps * k.KU * Mpad;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == UBR_F32) hipLaunchKernelGGL(pack_kernel<float>, dim3(blocks), dim3(256), 0, st, k);
+  else if (dtype == UBR_BF16) hipLaunchKernelGGL(pack_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, k);
+  else hipLaunchKernelGGL(pack_kernel<f16_t>, dim3(blocks), dim3(256), 0, st, k);
+  UBR_LAUNCH_CHECK("ubr_pack_weights");
+  return UBR_OK;
+}

@@ -1,0 +1,609 @@
+// HBM-bound kernels of the U-ResNet path: BatchNorm finalize/backward, BasicBlock tail
+// (relu(bn2)+shortcut+relu, models/common_layers.py:47-56) forward/backward, MaxPool2d(3,s,1)
+// forward/backward, channel sums.  NHWC, 16 bytes per lane per access; every thread keeps ONE
+// 16-byte channel unit for the whole launch (grid size is made a multiple of the units per
+// pixel), so per-channel constants live in registers and pixel indices need no division in the loop.
+// Per-channel reductions: registers -> fp64 LDS atomics -> fp64 global atomics.
+#include "ubr_common.h"
+#include "ubr_host.h"
+#include <float.h>
+
+namespace {
+
+static int gcd_i(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
+
+// blocks such that blocks*256 is a multiple of CU and the grid covers the work reasonably
+static int pick_blocks(int64_t npix, int CU, int max_blocks = 2048) {
+  const int mult = CU / gcd_i(256, CU);
+  int64_t want = (npix * CU + 255) / 256;
+  if (want > max_blocks) want = max_blocks;
+  if (want < 1) want = 1;
+  int64_t b = ((want + mult - 1) / mult) * mult;
+  return (int)b;
+}
+
+template <typename T> struct UnitIdx {
+  int c;          // channel unit of this thread
+  long p, pstep;  // first pixel and pixel step
+  __device__ UnitIdx(int CU) {
+    const long g = (long)blockIdx.x * 256 + threadIdx.x;
+    const long Tn = (long)gridDim.x * 256;
+    c = (int)(g % CU);
+    p = g / CU;
+    pstep = Tn / CU;
+  }
+};
+
+template <typename T> __device__ __forceinline__ void ldunit(const void* base, long pix, long ps, int c, float* f) {
+  constexpr int CPU = ET<T>::CPU;
+  const uint4 v = ldg16((const char*)base + (pix * ps + (long)c * CPU) * (16 / CPU));
+  ET<T>::unpack(v, f);
+}
+template <typename T> __device__ __forceinline__ void stunit(void* base, long pix, long ps, int c, const float* f) {
+  constexpr int CPU = ET<T>::CPU;
+  stg16((char*)base + (pix * ps + (long)c * CPU) * (16 / CPU), ET<T>::pack(f));
+}
+template <int CPU> __device__ __forceinline__ void ldconst(const float* a, int c, float* f) {
+#pragma unroll
+  for (int e = 0; e < CPU; ++e) f[e] = a[c * CPU + e];
+}
+
+// flush per-thread channel partials: LDS fp64 atomics, then one global fp64 atomic per channel
+template <int CPU, int NQ>
+__device__ __forceinline__ void flush_sums(const float (*acc)[CPU], int c, int C, double* lds, double* const* outs) {
+  for (int i = threadIdx.x; i < NQ * C; i += 256) lds[i] = 0.0;
+  __syncthreads();
+#pragma unroll
+  for (int qn = 0; qn < NQ; ++qn)
+#pragma unroll
+    for (int e = 0; e < CPU; ++e) atomicAdd(&lds[qn * C + c * CPU + e], (double)acc[qn][e]);
+  __syncthreads();
+  for (int i = threadIdx.x; i < NQ * C; i += 256) {
+    const int qn = i / C, ch = i - qn * C;
+    if (outs[qn] != nullptr) atomicAdd(&outs[qn][ch], lds[i]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// BasicBlock tail forward
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void tail_fwd_kernel(long npix, int CU, const void* c2, long c2_ps, const float* s2, const float* t2,
+                                                       const void* sc, long sc_ps, const float* sb, const float* tb, void* out, long out_ps) {
+  constexpr int CPU = ET<T>::CPU;
+  UnitIdx<T> ix(CU);
+  float a2[CPU], b2[CPU], ab[CPU], bb[CPU];
+  ldconst<CPU>(s2, ix.c, a2); ldconst<CPU>(t2, ix.c, b2);
+  const bool byp = sb != nullptr;
+  if (byp) { ldconst<CPU>(sb, ix.c, ab); ldconst<CPU>(tb, ix.c, bb); }
+  for (long p = ix.p; p < npix; p += ix.pstep) {
+    float v[CPU], s[CPU], o[CPU];
+    ldunit<T>(c2, p, c2_ps, ix.c, v);
+    ldunit<T>(sc, p, sc_ps, ix.c, s);
+#pragma unroll
+    for (int e = 0; e < CPU; ++e) {
+      const float r2 = fmaxf(fmaf(v[e], a2[e], b2[e]), 0.f);
+      const float sh = byp ? fmaf(s[e], ab[e], bb[e]) : s[e];
+      o[e] = fmaxf(r2 + sh, 0.f);
+    }
+    stunit<T>(out, p, out_ps, ix.c, o);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// BasicBlock tail backward
+// ------------------------------------------------------------------------------------------
+struct TailB {
+  long npix; int C, CU;
+  const void *go, *go2, *out, *c2, *cb;
+  long go_ps, go2_ps, out_ps, c2_ps, cb_ps;
+  const float *s2, *t2, *m2, *i2, *k1_2, *k2_2;
+  const float *sb, *mb, *ib, *k1_b, *k2_b;
+  double *red2, *redb;
+  void *g_c2, *g_sc; long g_c2_ps, g_sc_ps;
+};
+
+template <typename T, bool APPLY>
+__global__ __launch_bounds__(256) void tail_bwd_kernel(const TailB k) {
+  constexpr int CPU = ET<T>::CPU;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  UnitIdx<T> ix(k.CU);
+  const bool byp = k.cb != nullptr;
+  float s2[CPU], t2[CPU], m2[CPU], i2[CPU], mb[CPU], ib[CPU];
+  ldconst<CPU>(k.s2, ix.c, s2); ldconst<CPU>(k.t2, ix.c, t2); ldconst<CPU>(k.m2, ix.c, m2); ldconst<CPU>(k.i2, ix.c, i2);
+  if (byp) { ldconst<CPU>(k.mb, ix.c, mb); ldconst<CPU>(k.ib, ix.c, ib); }
+  float k12[CPU], k22[CPU], k1b[CPU], k2b[CPU], sb[CPU];
+  if (APPLY) {
+    ldconst<CPU>(k.k1_2, ix.c, k12); ldconst<CPU>(k.k2_2, ix.c, k22);
+    if (byp) { ldconst<CPU>(k.k1_b, ix.c, k1b); ldconst<CPU>(k.k2_b, ix.c, k2b); ldconst<CPU>(k.sb, ix.c, sb); }
+  }
+  float acc[4][CPU];
+#pragma unroll
+  for (int qn = 0; qn < 4; ++qn)
+#pragma unroll
+    for (int e = 0; e < CPU; ++e) acc[qn][e] = 0.f;
+
+  for (long p = ix.p; p < k.npix; p += ix.pstep) {
+    float g[CPU], o[CPU], c2[CPU], cb[CPU];
+    ldunit<T>(k.go, p, k.go_ps, ix.c, g);
+    if (k.go2 != nullptr) {
+      float g2[CPU];
+      ldunit<T>(k.go2, p, k.go2_ps, ix.c, g2);
+#pragma unroll
+      for (int e = 0; e < CPU; ++e) g[e] += g2[e];
+    }
+    ldunit<T>(k.out, p, k.out_ps, ix.c, o);
+    ldunit<T>(k.c2, p, k.c2_ps, ix.c, c2);
+    if (byp) ldunit<T>(k.cb, p, k.cb_ps, ix.c, cb);
+    float r2[CPU], rs[CPU];
+#pragma unroll
+    for (int e = 0; e < CPU; ++e) {
+      const float gz = o[e] > 0.f ? g[e] : 0.f;
+      const float gy2 = fmaf(c2[e], s2[e], t2[e]) > 0.f ? gz : 0.f;
+      const float xh2 = (c2[e] - m2[e]) * i2[e];
+      if (APPLY) {
+        r2[e] = s2[e] * (gy2 - k12[e] - xh2 * k22[e]);
+        if (byp) { const float xhb = (cb[e] - mb[e]) * ib[e]; rs[e] = sb[e] * (gz - k1b[e] - xhb * k2b[e]); }
+        else rs[e] = gz;
+      } else {
+        acc[0][e] += gy2; acc[1][e] += gy2 * xh2;
+        if (byp) { const float xhb = (cb[e] - mb[e]) * ib[e]; acc[2][e] += gz; acc[3][e] += gz * xhb; }
+      }
+    }
+    if (APPLY) {
+      stunit<T>(k.g_c2, p, k.g_c2_ps, ix.c, r2);
+      stunit<T>(k.g_sc, p, k.g_sc_ps, ix.c, rs);
+    }
+  }
+  if (!APPLY) {
+    double* outs[4] = {k.red2, k.red2 + k.C, byp ? k.redb : nullptr, byp ? k.redb + k.C : nullptr};
+    flush_sums<CPU, 4>(acc, ix.c, k.C, reinterpret_cast<double*>(smem), outs);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// BatchNorm(+ReLU) backward: a = max(bn(c), 0)
+// ------------------------------------------------------------------------------------------
+struct BnB {
+  long npix; int C, CU, relu;
+  const void *ga, *ga2, *c; long ga_ps, ga2_ps, c_ps;
+  const float *scale, *shift, *mean, *invstd, *k1, *k2;
+  double* red; void* gc; long gc_ps;
+};
+template <typename T, bool APPLY>
+__global__ __launch_bounds__(256) void bn_bwd_kernel(const BnB k) {
+  constexpr int CPU = ET<T>::CPU;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  UnitIdx<T> ix(k.CU);
+  float sc[CPU], sh[CPU], mu[CPU], is[CPU], k1[CPU], k2[CPU];
+  ldconst<CPU>(k.scale, ix.c, sc); ldconst<CPU>(k.shift, ix.c, sh); ldconst<CPU>(k.mean, ix.c, mu); ldconst<CPU>(k.invstd, ix.c, is);
+  if (APPLY) { ldconst<CPU>(k.k1, ix.c, k1); ldconst<CPU>(k.k2, ix.c, k2); }
+  float acc[2][CPU];
+#pragma unroll
+  for (int e = 0; e < CPU; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
+  for (long p = ix.p; p < k.npix; p += ix.pstep) {
+    float g[CPU], c[CPU], r[CPU];
+    ldunit<T>(k.ga, p, k.ga_ps, ix.c, g);
+    if (k.ga2 != nullptr) {
+      float g2[CPU];
+      ldunit<T>(k.ga2, p, k.ga2_ps, ix.c, g2);
+#pragma unroll
+      for (int e = 0; e < CPU; ++e) g[e] += g2[e];
+    }
+    ldunit<T>(k.c, p, k.c_ps, ix.c, c);
+#pragma unroll
+    for (int e = 0; e < CPU; ++e) {
+      const float gy = (!k.relu || fmaf(c[e], sc[e], sh[e]) > 0.f) ? g[e] : 0.f;
+      const float xh = (c[e] - mu[e]) * is[e];
+      if (APPLY) r[e] = sc[e] * (gy - k1[e] - xh * k2[e]);
+      else { acc[0][e] += gy; acc[1][e] += gy * xh; }
+    }
+    if (APPLY) stunit<T>(k.gc, p, k.gc_ps, ix.c, r);
+  }
+  if (!APPLY) {
+    double* outs[2] = {k.red, k.red + k.C};
+    flush_sums<CPU, 2>(acc, ix.c, k.C, reinterpret_cast<double*>(smem), outs);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void channel_sum_kernel(long npix, int C, int CU, const void* g, long g_ps, double* red) {
+  constexpr int CPU = ET<T>::CPU;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  UnitIdx<T> ix(CU);
+  float acc[1][CPU];
+#pragma unroll
+  for (int e = 0; e < CPU; ++e) acc[0][e] = 0.f;
+  for (long p = ix.p; p < npix; p += ix.pstep) {
+    float v[CPU];
+    ldunit<T>(g, p, g_ps, ix.c, v);
+#pragma unroll
+    for (int e = 0; e < CPU; ++e) acc[0][e] += v[e];
+  }
+  double* outs[1] = {red};
+  flush_sums<CPU, 1>(acc, ix.c, C, reinterpret_cast<double*>(smem), outs);
+}
+
+// ------------------------------------------------------------------------------------------
+// BatchNorm finalize kernels (tiny)
+// ------------------------------------------------------------------------------------------
+__global__ void bn_finalize_kernel(const double* stats, double count, const float* gamma, const float* beta,
+                                   float* rmean, float* rvar, long long* nbt, float momentum, float eps, int C,
+                                   float* scale, float* shift, float* mean, float* invstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && nbt != nullptr) *nbt += 1;
+  if (c >= C) return;
+  const double m = stats[c] / count;
+  double var = stats[C + c] / count - m * m;
+  if (var < 0.0) var = 0.0;
+  const double is = 1.0 / sqrt(var + (double)eps);
+  const float sc = (float)((double)gamma[c] * is);
+  scale[c] = sc;
+  shift[c] = (float)((double)beta[c] - m * (double)gamma[c] * is);
+  mean[c] = (float)m;
+  invstd[c] = (float)is;
+  if (rmean != nullptr) {
+    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+    rmean[c] = (float)((1.0 - (double)momentum) * (double)rmean[c] + (double)momentum * m);
+    rvar[c] = (float)((1.0 - (double)momentum) * (double)rvar[c] + (double)momentum * unb);
+  }
+}
+__global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, const float* rmean, const float* rvar,
+                                      float eps, int C, float* scale, float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float is = 1.0f / sqrtf(rvar[c] + eps);
+  const float sc = gamma[c] * is;
+  scale[c] = sc;
+  shift[c] = beta[c] - rmean[c] * sc;
+}
+__global__ void bn_bwd_finalize_kernel(const double* red, double count, int C, float* dgamma, float* dbeta, int accumulate,
+                                       float* k1, float* k2) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double sg = red[c], sgx = red[C + c];
+  if (dgamma != nullptr) dgamma[c] = accumulate ? dgamma[c] + (float)sgx : (float)sgx;
+  if (dbeta != nullptr) dbeta[c] = accumulate ? dbeta[c] + (float)sg : (float)sg;
+  k1[c] = (float)(sg / count);
+  k2[c] = (float)(sgx / count);
+}
+__global__ void cast_f64_kernel(const double* src, float* dst, int n, double scale, int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float v = (float)(src[i] * scale);
+  dst[i] = accumulate ? dst[i] + v : v;
+}
+
+// ------------------------------------------------------------------------------------------
+// MaxPool2d(3, stride, padding=1)
+// ------------------------------------------------------------------------------------------
+struct PoolK {
+  int N, H, W, OH, OW, C, CU, stride;
+  const void* x; long x_ps;
+  const float *scale, *shift, *lo;
+  void* pooled; long p_ps;
+  void* xcopy; long xc_ps;
+  const void* gp; long gp_ps;
+  const void* ge; long ge_ps;
+  void* gx; long gx_ps;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const PoolK k) {
+  constexpr int CPU = ET<T>::CPU;
+  UnitIdx<T> ix(k.CU);
+  const bool xf = k.scale != nullptr;
+  float sc[CPU], sh[CPU], lo[CPU];
+  if (xf) { ldconst<CPU>(k.scale, ix.c, sc); ldconst<CPU>(k.shift, ix.c, sh); ldconst<CPU>(k.lo, ix.c, lo); }
+  const long npix = (long)k.N * k.OH * k.OW;
+  for (long p = ix.p; p < npix; p += ix.pstep) {
+    const int ox = (int)(p % k.OW);
+    const long r = p / k.OW;
+    const int oy = (int)(r % k.OH);
+    const int n = (int)(r / k.OH);
+    float m[CPU];
+#pragma unroll
+    for (int e = 0; e < CPU; ++e) m[e] = -FLT_MAX;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * k.stride - 1 + ky;
+      if ((unsigned)iy >= (unsigned)k.H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int jx = ox * k.stride - 1 + kx;
+        if ((unsigned)jx >= (unsigned)k.W) continue;
+        const long ip = ((long)n * k.H + iy) * k.W + jx;
+        float v[CPU];
+        ldunit<T>(k.x, ip, k.x_ps, ix.c, v);
+        if (xf) {
+#pragma unroll
+          for (int e = 0; e < CPU; ++e) v[e] = fmaxf(fmaf(v[e], sc[e], sh[e]), lo[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < CPU; ++e) m[e] = fmaxf(m[e], v[e]);
+        // each stride-2 window owns the 2x2 input pixels (2oy..2oy+1, 2ox..2ox+1) = taps ky,kx in {1,2}
+        if (k.xcopy != nullptr && ky >= 1 && kx >= 1) stunit<T>(k.xcopy, ip, k.xc_ps, ix.c, v);
+      }
+    }
+    stunit<T>(k.pooled, p, k.p_ps, ix.c, m);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const PoolK k) {
+  constexpr int CPU = ET<T>::CPU;
+  UnitIdx<T> ix(k.CU);
+  const bool xf = k.scale != nullptr;
+  float sc[CPU], sh[CPU], lo[CPU];
+  if (xf) { ldconst<CPU>(k.scale, ix.c, sc); ldconst<CPU>(k.shift, ix.c, sh); ldconst<CPU>(k.lo, ix.c, lo); }
+  const long npix = (long)k.N * k.H * k.W;
+  const int s = k.stride;
+  for (long p = ix.p; p < npix; p += ix.pstep) {
+    const int jx = (int)(p % k.W);
+    const long r = p / k.W;
+    const int iy = (int)(r % k.H);
+    const int n = (int)(r / k.H);
+    float g[CPU];
+    if (k.ge != nullptr) ldunit<T>(k.ge, p, k.ge_ps, ix.c, g);
+    else {
+#pragma unroll
+      for (int e = 0; e < CPU; ++e) g[e] = 0.f;
+    }
+    // windows (oy,ox) whose 3x3 footprint contains (iy,jx): oy*s-1 <= iy <= oy*s+1
+    const int oy_lo = (iy - 1 + s - 1 >= 0) ? (iy - 1 + s - 1) / s : 0;   // ceil((iy-1)/s), clamped at 0
+    const int oy_hi = min((iy + 1) / s, k.OH - 1);
+    const int ox_lo = (jx - 1 + s - 1 >= 0) ? (jx - 1 + s - 1) / s : 0;
+    const int ox_hi = min((jx + 1) / s, k.OW - 1);
+    for (int oy = oy_lo; oy <= oy_hi; ++oy)
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        float best[CPU]; bool me[CPU];
+#pragma unroll
+        for (int e = 0; e < CPU; ++e) { best[e] = -FLT_MAX; me[e] = false; }
+        bool first = true;
+        for (int ky = 0; ky < 3; ++ky) {
+          const int yy = oy * s - 1 + ky;
+          if ((unsigned)yy >= (unsigned)k.H) continue;
+          for (int kx = 0; kx < 3; ++kx) {
+            const int xx = ox * s - 1 + kx;
+            if ((unsigned)xx >= (unsigned)k.W) continue;
+            float v[CPU];
+            ldunit<T>(k.x, ((long)n * k.H + yy) * k.W + xx, k.x_ps, ix.c, v);
+            if (xf) {
+#pragma unroll
+              for (int e = 0; e < CPU; ++e) v[e] = fmaxf(fmaf(v[e], sc[e], sh[e]), lo[e]);
+            }
+            const bool here = (yy == iy) && (xx == jx);
+#pragma unroll
+            for (int e = 0; e < CPU; ++e)
+              if (first || v[e] > best[e]) { best[e] = v[e]; me[e] = here; }   // strict >: first maximum wins (ATen)
+            first = false;
+          }
+        }
+        float gp[CPU];
+        ldunit<T>(k.gp, ((long)n * k.OH + oy) * k.OW + ox, k.gp_ps, ix.c, gp);
+#pragma unroll
+        for (int e = 0; e < CPU; ++e) if (me[e]) g[e] += gp[e];
+      }
+    stunit<T>(k.gx, p, k.gx_ps, ix.c, g);
+  }
+}
+
+template <typename K> struct Dispatch3 {};
+
+}  // namespace
+
+#define UBR_DT_SWITCH(dtype, CALL)                    \
+  switch (dtype) {                                    \
+    case UBR_F32: { typedef float TT; CALL; } break;  \
+    case UBR_BF16: { typedef bf16_t TT; CALL; } break;\
+    default: { typedef f16_t TT; CALL; } break;       \
+  }
+
+static int check_nhwc(const char* who, int dtype, int64_t npix, int C, const void* p, int64_t ps) {
+  UBR_CHECK(ubr_dtype_ok(dtype), "%s: bad dtype", who);
+  const int esz = ubr_esize(dtype);
+  UBR_CHECK(npix > 0 && C > 0 && C % ubr_cpu(dtype) == 0, "%s: bad extent npix=%ld C=%d", who, (long)npix, C);
+  UBR_CHECK(p != nullptr && ubr_aligned16(p) && ps >= C && (ps * esz) % 16 == 0, "%s: tensor must be non-null, 16-byte aligned, pixel stride %ld >= C and 16-byte multiple", who, (long)ps);
+  return UBR_OK;
+}
+#define UBR_TRY(x) do { int rc__ = (x); if (rc__ != UBR_OK) return rc__; } while (0)
+
+extern "C" int ubr_block_tail_fwd(int dtype, int64_t npix, int C, const void* c2, int64_t c2_ps, const float* scale2,
+                                  const float* shift2, const void* sc, int64_t sc_ps, const float* scale_b,
+                                  const float* shift_b, void* out, int64_t out_ps, void* stream) {
+  UBR_TRY(check_nhwc("ubr_block_tail_fwd(c2)", dtype, npix, C, c2, c2_ps));
+  UBR_TRY(check_nhwc("ubr_block_tail_fwd(sc)", dtype, npix, C, sc, sc_ps));
+  UBR_TRY(check_nhwc("ubr_block_tail_fwd(out)", dtype, npix, C, out, out_ps));
+  UBR_CHECK(scale2 && shift2 && ((scale_b == nullptr) == (shift_b == nullptr)), "ubr_block_tail_fwd: bad affine pointers");
+  const int CU = C / ubr_cpu(dtype);
+  const int blocks = pick_blocks(npix, CU);
+  UBR_DT_SWITCH(dtype, hipLaunchKernelGGL(tail_fwd_kernel<TT>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (long)npix, CU, c2, (long)c2_ps,
+                                          scale2, shift2, sc, (long)sc_ps, scale_b, shift_b, out, (long)out_ps));
+  UBR_LAUNCH_CHECK("ubr_block_tail_fwd");
+  return UBR_OK;
+}
+
+static int tail_bwd_common(bool apply, int dtype, int64_t npix, int C, const void* go, int64_t go_ps, const void* go2, int64_t go2_ps,
+                           const void* out, int64_t out_ps, const void* c2, int64_t c2_ps,
+                           const float* scale2, const float* shift2, const float* mean2, const float* invstd2,
+                           const float* k1_2, const float* k2_2,
+                           const void* cb, int64_t cb_ps, const float* scale_b, const float* mean_b, const float* invstd_b,
+                           const float* k1_b, const float* k2_b, double* red2, double* red_b,
+                           void* g_c2, int64_t g_c2_ps, void* g_sc, int64_t g_sc_ps, void* stream) {
+  const char* who = apply ? "ubr_block_tail_bwd_apply" : "ubr_block_tail_bwd_reduce";
+  UBR_TRY(check_nhwc(who, dtype, npix, C, go, go_ps));
+  if (go2) UBR_TRY(check_nhwc(who, dtype, npix, C, go2, go2_ps));
+  UBR_TRY(check_nhwc(who, dtype, npix, C, out, out_ps));
+  UBR_TRY(check_nhwc(who, dtype, npix, C, c2, c2_ps));
+  if (cb) UBR_TRY(check_nhwc(who, dtype, npix, C, cb, cb_ps));
+  UBR_CHECK(scale2 && shift2 && mean2 && invstd2, "%s: null bn2 constants", who);
+  if (cb) UBR_CHECK(mean_b && invstd_b, "%s: null bnpass constants", who);
+  if (apply) {
+    UBR_TRY(check_nhwc(who, dtype, npix, C, g_c2, g_c2_ps));
+    UBR_TRY(check_nhwc(who, dtype, npix, C, g_sc, g_sc_ps));
+    UBR_CHECK(k1_2 && k2_2 && (!cb || (k1_b && k2_b && scale_b)), "%s: null backward constants", who);
+  } else {
+    UBR_CHECK(red2 && (!cb || red_b), "%s: null reduction buffer", who);
+  }
+  TailB k{};
+  k.npix = npix; k.C = C; k.CU = C / ubr_cpu(dtype);
+  k.go = go; k.go2 = go2; k.out = out; k.c2 = c2; k.cb = cb;
+  k.go_ps = go_ps; k.go2_ps = go2_ps; k.out_ps = out_ps; k.c2_ps = c2_ps; k.cb_ps = cb_ps;
+  k.s2 = scale2; k.t2 = shift2; k.m2 = mean2; k.i2 = invstd2; k.k1_2 = k1_2; k.k2_2 = k2_2;
+  k.sb = scale_b; k.mb = mean_b; k.ib = invstd_b; k.k1_b = k1_b; k.k2_b = k2_b;
+  k.red2 = red2; k.redb = red_b; k.g_c2 = g_c2; k.g_sc = g_sc; k.g_c2_ps = g_c2_ps; k.g_sc_ps = g_sc_ps;
+  const int blocks = pick_blocks(npix, k.CU, apply ? 2048 : 1024);
+  const size_t lds = apply ? 0 : (size_t)4 * C * sizeof(double);
+  if (apply) { UBR_DT_SWITCH(dtype, hipLaunchKernelGGL((tail_bwd_kernel<TT, true>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, k)); }
+  else { UBR_DT_SWITCH(dtype, hipLaunchKernelGGL((tail_bwd_kernel<TT, false>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, k)); }
+  UBR_LAUNCH_CHECK(who);
+  return UBR_OK;
+}
+
+extern "C" int ubr_block_tail_bwd_reduce(int dtype, int64_t npix, int C, const void* go, int64_t go_ps, const void* go2, int64_t go2_ps,
+                                         const void* out, int64_t out_ps, const void* c2, int64_t c2_ps,
+                                         const float* scale2, const float* shift2, const float* mean2, const float* invstd2,
+                                         const void* cb, int64_t cb_ps, const float* mean_b, const float* invstd_b,
+                                         double* red2, double* red_b, void* stream) {
+  return tail_bwd_common(false, dtype, npix, C, go, go_ps, go2, go2_ps, out, out_ps, c2, c2_ps, scale2, shift2, mean2, invstd2,
+                         nullptr, nullptr, cb, cb_ps, nullptr, mean_b, invstd_b, nullptr, nullptr, red2, red_b,
+                         nullptr, 0, nullptr, 0, stream);
+}
+extern "C" int ubr_block_tail_bwd_apply(int dtype, int64_t npix, int C, const void* go, int64_t go_ps, const void* go2, int64_t go2_ps,
+                                        const void* out, int64_t out_ps, const void* c2, int64_t c2_ps,
+                                        const float* scale2, const float* shift2, const float* mean2, const float* invstd2,
+                                        const float* k1_2, const float* k2_2,
+                                        const void* cb, int64_t cb_ps, const float* scale_b, const float* mean_b, const float* invstd_b,
+                                        const float* k1_b, const float* k2_b,
+                                        void* g_c2, int64_t g_c2_ps, void* g_sc, int64_t g_sc_ps, void* stream) {
+  return tail_bwd_common(true, dtype, npix, C, go, go_ps, go2, go2_ps, out, out_ps, c2, c2_ps, scale2, shift2, mean2, invstd2,
+                         k1_2, k2_2, cb, cb_ps, scale_b, mean_b, invstd_b, k1_b, k2_b, nullptr, nullptr,
+                         g_c2, g_c2_ps, g_sc, g_sc_ps, stream);
+}
+
+static int bn_bwd_common(bool apply, int dtype, int64_t npix, int C, const void* ga, int64_t ga_ps, const void* ga2, int64_t ga2_ps,
+                         const void* c, int64_t c_ps, const float* scale, const float* shift, const float* mean,
+                         const float* invstd, int relu, const float* k1, const float* k2, double* red,
+                         void* gc, int64_t gc_ps, void* stream) {
+  const char* who = apply ? "ubr_bn_bwd_apply" : "ubr_bn_bwd_reduce";
+  UBR_TRY(check_nhwc(who, dtype, npix, C, ga, ga_ps));
+  if (ga2) UBR_TRY(check_nhwc(who, dtype, npix, C, ga2, ga2_ps));
+  UBR_TRY(check_nhwc(who, dtype, npix, C, c, c_ps));
+  UBR_CHECK(scale && shift && mean && invstd, "%s: null bn constants", who);
+  if (apply) { UBR_TRY(check_nhwc(who, dtype, npix, C, gc, gc_ps)); UBR_CHECK(k1 && k2, "%s: null k1/k2", who); }
+  else UBR_CHECK(red != nullptr, "%s: null reduction buffer", who);
+  BnB k{};
+  k.npix = npix; k.C = C; k.CU = C / ubr_cpu(dtype); k.relu = relu;
+  k.ga = ga; k.ga2 = ga2; k.c = c; k.ga_ps = ga_ps; k.ga2_ps = ga2_ps; k.c_ps = c_ps;
+  k.scale = scale; k.shift = shift; k.mean = mean; k.invstd = invstd; k.k1 = k1; k.k2 = k2; k.red = red; k.gc = gc; k.gc_ps = gc_ps;
+  const int blocks = pick_blocks(npix, k.CU, apply ? 2048 : 1024);
+  const size_t lds = apply ? 0 : (size_t)2 * C * sizeof(double);
+  if (apply) { UBR_DT_SWITCH(dtype, hipLaunchKernelGGL((bn_bwd_kernel<TT, true>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, k)); }
+  else { UBR_DT_SWITCH(dtype, hipLaunchKernelGGL((bn_bwd_kernel<TT, false>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, k)); }
+  UBR_LAUNCH_CHECK(who);
+  return UBR_OK;
+}
+extern "C" int ubr_bn_bwd_reduce(int dtype, int64_t npix, int C, const void* ga, int64_t ga_ps, const void* ga2, int64_t ga2_ps,
+                                 const void* c, int64_t c_ps, const float* scale, const float* shift, const float* mean,
+                                 const float* invstd, int relu, double* red, void* stream) {
+  return bn_bwd_common(false, dtype, npix, C, ga, ga_ps, ga2, ga2_ps, c, c_ps, scale, shift, mean, invstd, relu, nullptr, nullptr, red, nullptr, 0, stream);
+}
+extern "C" int ubr_bn_bwd_apply(int dtype, int64_t npix, int C, const void* ga, int64_t ga_ps, const void* ga2, int64_t ga2_ps,
+                                const void* c, int64_t c_ps, const float* scale, const float* shift, const float* mean,
+                                const float* invstd, int relu, const float* k1, const float* k2,
+                                void* gc, int64_t gc_ps, void* stream) {
+  return bn_bwd_common(true, dtype, npix, C, ga, ga_ps, ga2, ga2_ps, c, c_ps, scale, shift, mean, invstd, relu, k1, k2, nullptr, gc, gc_ps, stream);
+}
+
+extern "C" int ubr_channel_sum(int dtype, int64_t npix, int C, const void* g, int64_t g_ps, double* red, void* stream) {
+  UBR_TRY(check_nhwc("ubr_channel_sum", dtype, npix, C, g, g_ps));
+  UBR_CHECK(red != nullptr, "ubr_channel_sum: null output");
+  const int CU = C / ubr_cpu(dtype);
+  const int blocks = pick_blocks(npix, CU, 1024);
+  UBR_DT_SWITCH(dtype, hipLaunchKernelGGL(channel_sum_kernel<TT>, dim3(blocks), dim3(256), (size_t)C * sizeof(double), (hipStream_t)stream,
+                                          (long)npix, C, CU, g, (long)g_ps, red));
+  UBR_LAUNCH_CHECK("ubr_channel_sum");
+  return UBR_OK;
+}
+
+extern "C" int ubr_bn_finalize(const double* stats, double count, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                               float momentum, float eps, int C,
+                               float* scale, float* shift, float* mean, float* invstd, void* stream) {
+  UBR_CHECK(stats && gamma && beta && scale && shift && mean && invstd && C > 0 && count >= 1.0, "ubr_bn_finalize: bad arguments");
+  UBR_CHECK((running_mean == nullptr) == (running_var == nullptr), "ubr_bn_finalize: running stats must come together");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ubr_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, stats, count, gamma, beta,
+                     running_mean, running_var, (long long*)num_batches_tracked, momentum, eps, C, scale, shift, mean, invstd);
+  UBR_LAUNCH_CHECK("ubr_bn_finalize");
+  return UBR_OK;
+}
+extern "C" int ubr_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
+                                  const float* running_var, float eps, int C, float* scale, float* shift, void* stream) {
+  UBR_CHECK(gamma && beta && running_mean && running_var && scale && shift && C > 0, "ubr_bn_eval_affine: bad arguments");
+  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(ubr_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, gamma, beta, running_mean, running_var, eps, C, scale, shift);
+  UBR_LAUNCH_CHECK("ubr_bn_eval_affine");
+  return UBR_OK;
+}
+extern "C" int ubr_bn_bwd_finalize(const double* red, double count, const float* scale, const float* invstd,
+                                   int C, float* dgamma, float* dbeta, int accumulate, float* k1, float* k2, void* stream) {
+  (void)scale; (void)invstd;
+  UBR_CHECK(red && k1 && k2 && C > 0 && count >= 1.0, "ubr_bn_bwd_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ubr_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, red, count, C, dgamma, dbeta, accumulate, k1, k2);
+  UBR_LAUNCH_CHECK("ubr_bn_bwd_finalize");
+  return UBR_OK;
+}
+extern "C" int ubr_cast_f64_to_f32(const double* src, float* dst, int n, double scale, int accumulate, void* stream) {
+  UBR_CHECK(src && dst && n > 0, "ubr_cast_f64_to_f32: bad arguments");
+  hipLaunchKernelGGL(cast_f64_kernel, dim3(ubr_cdiv(n, 128)), dim3(128), 0, (hipStream_t)stream, src, dst, n, scale, accumulate);
+  UBR_LAUNCH_CHECK("ubr_cast_f64_to_f32");
+  return UBR_OK;
+}
+extern "C" int ubr_zero(void* p, int64_t bytes, void* stream) {
+  UBR_CHECK(p != nullptr && bytes > 0, "ubr_zero: bad arguments");
+  hipError_t e = hipMemsetAsync(p, 0, (size_t)bytes, (hipStream_t)stream);
+  if (e != hipSuccess) { ubr_set_error("ubr_zero: %s", hipGetErrorString(e)); return UBR_ELAUNCH; }
+  return UBR_OK;
+}
+
+static int pool_common(bool bwd, int dtype, int N, int H, int W, int C, int stride, const void* x, int64_t x_ps, ubr_chan_affine xf,
+                       void* pooled, int64_t p_ps, void* xcopy, int64_t xc_ps,
+                       const void* gp, int64_t gp_ps, const void* ge, int64_t ge_ps, void* gx, int64_t gx_ps, void* stream) {
+  const char* who = bwd ? "ubr_maxpool_bwd" : "ubr_maxpool_fwd";
+  UBR_CHECK(N > 0 && H > 0 && W > 0 && (stride == 1 || stride == 2), "%s: bad extents", who);
+  const int OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
+  const int64_t npix_in = (int64_t)N * H * W, npix_out = (int64_t)N * OH * OW;
+  UBR_TRY(check_nhwc(who, dtype, npix_in, C, x, x_ps));
+  const bool hx = xf.scale != nullptr;
+  UBR_CHECK(hx == (xf.shift != nullptr) && hx == (xf.lo != nullptr), "%s: xf needs scale, shift and lo together", who);
+  PoolK k{};
+  k.N = N; k.H = H; k.W = W; k.OH = OH; k.OW = OW; k.C = C; k.CU = C / ubr_cpu(dtype); k.stride = stride;
+  k.x = x; k.x_ps = x_ps; k.scale = xf.scale; k.shift = xf.shift; k.lo = xf.lo;
+  if (!bwd) {
+    UBR_TRY(check_nhwc(who, dtype, npix_out, C, pooled, p_ps));
+    if (xcopy) {
+      UBR_CHECK(stride == 2 && H % 2 == 0 && W % 2 == 0, "%s: xcopy needs stride 2 and even H, W", who);
+      UBR_TRY(check_nhwc(who, dtype, npix_in, C, xcopy, xc_ps));
+    }
+    k.pooled = pooled; k.p_ps = p_ps; k.xcopy = xcopy; k.xc_ps = xc_ps;
+    const int blocks = pick_blocks(npix_out, k.CU);
+    UBR_DT_SWITCH(dtype, hipLaunchKernelGGL(maxpool_fwd_kernel<TT>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, k));
+  } else {
+    UBR_TRY(check_nhwc(who, dtype, npix_out, C, gp, gp_ps));
+    if (ge) UBR_TRY(check_nhwc(who, dtype, npix_in, C, ge, ge_ps));
+    UBR_TRY(check_nhwc(who, dtype, npix_in, C, gx, gx_ps));
+    k.gp = gp; k.gp_ps = gp_ps; k.ge = ge; k.ge_ps = ge_ps; k.gx = gx; k.gx_ps = gx_ps;
+    const int blocks = pick_blocks(npix_in, k.CU);
+    UBR_DT_SWITCH(dtype, hipLaunchKernelGGL(maxpool_bwd_kernel<TT>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, k));
+  }
+  UBR_LAUNCH_CHECK(who);
+  return UBR_OK;
+}
+extern "C" int ubr_maxpool_fwd(int dtype, int N, int H, int W, int C, int stride, const void* x, int64_t x_ps,
+                               ubr_chan_affine xf, void* pooled, int64_t p_ps, void* xcopy, int64_t xc_ps, void* stream) {
+  return pool_common(false, dtype, N, H, W, C, stride, x, x_ps, xf, pooled, p_ps, xcopy, xc_ps, nullptr, 0, nullptr, 0, nullptr, 0, stream);
+}
+extern "C" int ubr_maxpool_bwd(int dtype, int N, int H, int W, int C, int stride, const void* x, int64_t x_ps,
+                               ubr_chan_affine xf, const void* g_pooled, int64_t gp_ps, const void* g_extra, int64_t ge_ps,
+                               void* gx, int64_t gx_ps, void* stream) {
+  return pool_common(true, dtype, N, H, W, C, stride, x, x_ps, xf, nullptr, 0, nullptr, 0, g_pooled, gp_ps, g_extra, ge_ps, gx, gx_ps, stream);
+}

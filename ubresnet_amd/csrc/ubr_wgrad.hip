@@ -1,0 +1,345 @@
+// Weight gradients on MFMA with the pixel axis as the GEMM K dimension (gfx950).
+//
+// Replaces the weight half of autograd's ConvolutionBackward for every conv / deconv of the
+// path (reference layers: models/common_layers.py:13-15,33,125; models/ub_uresnet.py:60,64).
+//   dW[t][co][ci] = sum_pixels g[p][co] * xform(x)[p + tap_t][ci]
+// D[co][ci] += G^T[co][p] * X[p][ci]: both operands need "K contiguous per lane", i.e. the
+// TRANSPOSE of the NHWC tiles held in LDS.  For 16-bit types that transpose is free:
+// ds_read_b64_tr_b16 delivers a 4-pixel x 16-channel block column-major, and because every lane
+// supplies its own row address a tap shift is just a different row -- no alignment constraint.
+// fp32 (parity path) uses four scalar LDS reads per fragment and v_mfma_f32_16x16x4_f32.
+//
+// A workgroup owns (cout tile, cin tile, tap group), walks pixel tiles with a grid stride
+// (split-K), keeps all its dW partials in registers, and finally writes ONE fp32 slab;
+// ubr_wgrad_reduce sums slabs in fixed order -> bitwise reproducible, no float atomics.
+#include "ubr_common.h"
+#include "ubr_host.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+struct WgK {
+  const char* x; long x_sn, x_sy, x_sx;
+  const float *in_scale, *in_shift, *in_lo;
+  const char* g; long g_sn, g_sy, g_sx;
+  float* slabs;
+  int N, H, W, GH, GW, Cin, Cout_pad;
+  int ntaps, S, iy0, ix0, dymin, dxmin, HH, HW;
+  int TH, tiles_x, tiles_y, ntiles;
+  int pixbG, pixbX, x_off;
+  int n_cot;
+  int8_t dy[UBR_MAX_TAPS], dx[UBR_MAX_TAPS];
+};
+
+// transposed fragment: this lane's 4 units-of-K for channel (lane&15); 16-bit types
+__device__ __forceinline__ uint4 tr_frag16(const char* p0, int pstride4) {
+  typedef __attribute__((address_space(3))) s16x4_t* lds_p;
+  s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p0));
+  s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p0 + pstride4));
+  uint2 a = __builtin_bit_cast(uint2, lo), b = __builtin_bit_cast(uint2, hi);
+  return make_uint4(a.x, a.y, b.x, b.y);
+}
+__device__ __forceinline__ uint4 sc_frag32(const char* p0, int pstride) {
+  return make_uint4(*reinterpret_cast<const uint32_t*>(p0), *reinterpret_cast<const uint32_t*>(p0 + pstride),
+                    *reinterpret_cast<const uint32_t*>(p0 + 2 * pstride), *reinterpret_cast<const uint32_t*>(p0 + 3 * pstride));
+}
+
+template <typename T, int MA, int NB, int TPG>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgK k) {
+  constexpr int CPU = ET<T>::CPU;
+  constexpr int ESZ = 16 / CPU;
+  constexpr int TCO = MA * 16, TCI = NB * 16;
+  constexpr int UG = TCO / CPU, UX = TCI / CPU;   // 16-byte units per pixel
+  constexpr int PXS = 4 * CPU;                    // pixels per K-step (32 or 16)
+  constexpr int KSR = 32 / PXS;                   // K-steps per 32-pixel tile row
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* gl = smem;
+  char* xl = smem + k.x_off;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, l16 = lane & 15;
+  const int cot = blockIdx.y % k.n_cot, cit = blockIdx.y / k.n_cot;
+  const int co0 = cot * TCO, ci0 = cit * TCI;
+  const int t0 = blockIdx.z * TPG;
+  const bool has_xf = k.in_scale != nullptr;
+
+  f32x4 acc[TPG][MA][NB];
+#pragma unroll
+  for (int t = 0; t < TPG; ++t)
+#pragma unroll
+    for (int a = 0; a < MA; ++a)
+#pragma unroll
+      for (int b = 0; b < NB; ++b) acc[t][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int tile = blockIdx.x; tile < k.ntiles; tile += gridDim.x) {
+    int tt = tile;
+    const int tx = tt % k.tiles_x; tt /= k.tiles_x;
+    const int ty = tt % k.tiles_y;
+    const int n = tt / k.tiles_y;
+    const int oy0 = ty * k.TH, ox0 = tx * 32;
+    __syncthreads();   // previous tile fully consumed
+    // ---- stage gradient tile [TH*32 px][TCO] ----
+    {
+      const char* gn = k.g + (long)n * k.g_sn;
+      const int nitems = k.TH * 32 * UG;
+      for (int i = tid; i < nitems; i += 256) {
+        const int c = i % UG, px = i / UG;
+        const int gy = oy0 + (px >> 5), gx = ox0 + (px & 31);
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (gy < k.GH && gx < k.GW) v = ldg16(gn + (long)gy * k.g_sy + (long)gx * k.g_sx + (long)(co0 + c * CPU) * ESZ);
+        *reinterpret_cast<uint4*>(gl + px * k.pixbG + c * 16) = v;
+      }
+    }
+    // ---- stage input halo [HH*HW px][TCI], transformed, zero padded ----
+    {
+      const char* xn = k.x + (long)n * k.x_sn;
+      const int hy0 = oy0 * k.S + k.iy0 + k.dymin, hx0 = ox0 * k.S + k.ix0 + k.dxmin;
+      const int nitems = k.HH * k.HW * UX;
+      for (int i = tid; i < nitems; i += 256) {
+        const int c = i % UX, px = i / UX;
+        const int hy = px / k.HW, hx = px - hy * k.HW;
+        const int iy = hy0 + hy, ix = hx0 + hx;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if ((unsigned)iy < (unsigned)k.H && (unsigned)ix < (unsigned)k.W) {
+          const int ch0 = ci0 + c * CPU;
+          v = ldg16(xn + (long)iy * k.x_sy + (long)ix * k.x_sx + (long)ch0 * ESZ);
+          if (has_xf) {
+            float f[CPU];
+            ET<T>::unpack(v, f);
+#pragma unroll
+            for (int e = 0; e < CPU; ++e) f[e] = fmaxf(fmaf(f[e], k.in_scale[ch0 + e], k.in_shift[ch0 + e]), k.in_lo[ch0 + e]);
+            v = ET<T>::pack(f);
+          }
+        }
+        *reinterpret_cast<uint4*>(xl + px * k.pixbX + c * 16) = v;
+      }
+    }
+    __syncthreads();
+    // ---- MFMA: each wave takes rows wave, wave+4, ... ----
+    for (int r = wave; r < k.TH; r += 4) {
+#pragma unroll
+      for (int ks = 0; ks < KSR; ++ks) {
+        uint4 A[MA];
+        if constexpr (CPU == 8) {
+          const char* p = gl + (r * 32 + 8 * q + (l16 >> 2)) * k.pixbG + (l16 & 3) * 8;
+#pragma unroll
+          for (int a = 0; a < MA; ++a) A[a] = tr_frag16(p + a * 32, 4 * k.pixbG);
+        } else {
+          const char* p = gl + (r * 32 + ks * 16 + 4 * q) * k.pixbG + l16 * 4;
+#pragma unroll
+          for (int a = 0; a < MA; ++a) A[a] = sc_frag32(p + a * 64, k.pixbG);
+        }
+#pragma unroll
+        for (int t = 0; t < TPG; ++t) {
+          if (t0 + t < k.ntaps) {
+            const int ddy = k.dy[t0 + t] - k.dymin, ddx = k.dx[t0 + t] - k.dxmin;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+              uint4 B;
+              if constexpr (CPU == 8) {
+                const char* p = xl + ((r * k.S + ddy) * k.HW + (8 * q + (l16 >> 2)) * k.S + ddx) * k.pixbX + (l16 & 3) * 8 + b * 32;
+                B = tr_frag16(p, 4 * k.S * k.pixbX);
+              } else {
+                const char* p = xl + ((r * k.S + ddy) * k.HW + (ks * 16 + 4 * q) * k.S + ddx) * k.pixbX + l16 * 4 + b * 64;
+                B = sc_frag32(p, k.S * k.pixbX);
+              }
+#pragma unroll
+              for (int a = 0; a < MA; ++a) acc[t][a][b] = mma_step<T>(acc[t][a][b], A[a], B);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  // ---- cross-wave sum in fixed order (wave 0,1,2,3) through LDS, then one slab write ----
+  float* red = reinterpret_cast<float*>(smem);
+  for (int w = 0; w < 4; ++w) {
+    __syncthreads();
+    if (wave == w) {
+#pragma unroll
+      for (int t = 0; t < TPG; ++t)
+#pragma unroll
+        for (int a = 0; a < MA; ++a)
+#pragma unroll
+          for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float* p = red + (((t * MA + a) * NB + b) * 4 + r) * 64 + lane;
+              *p = (w == 0) ? acc[t][a][b][r] : (*p + acc[t][a][b][r]);
+            }
+    }
+  }
+  __syncthreads();
+  float* slab = k.slabs + (long)blockIdx.x * k.ntaps * k.Cout_pad * k.Cin;
+  for (int s = wave; s < TPG * MA * NB; s += 4) {
+    const int b = s % NB, a = (s / NB) % MA, t = s / (NB * MA);
+    if (t0 + t < k.ntaps) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + a * 16 + 4 * q + r, ci = ci0 + b * 16 + l16;
+        slab[((long)(t0 + t) * k.Cout_pad + co) * k.Cin + ci] = red[(s * 4 + r) * 64 + lane];
+      }
+    }
+  }
+}
+
+struct WPlan { int MA, NB, TPG, TH, HH, HW, pixbG, pixbX, x_off, tiles_x, tiles_y, ntiles, nsplit, gy, gz; size_t lds; };
+
+static int wgrad_plan(const ubr_wgrad_desc* d, WPlan* p) {
+  UBR_CHECK(d != nullptr, "ubr_wgrad: null descriptor");
+  UBR_CHECK(ubr_dtype_ok(d->dtype), "ubr_wgrad: bad dtype");
+  const int esz = ubr_esize(d->dtype);
+  UBR_CHECK(d->N > 0 && d->H > 0 && d->W > 0 && d->GH > 0 && d->GW > 0, "ubr_wgrad: empty extent");
+  UBR_CHECK(d->Cin > 0 && d->Cin % 16 == 0 && d->Cout > 0 && d->Cout % 16 == 0, "ubr_wgrad: channels must be multiples of 16 (Cin=%d Cout=%d)", d->Cin, d->Cout);
+  UBR_CHECK(d->ntaps >= 1 && d->ntaps <= UBR_MAX_TAPS, "ubr_wgrad: ntaps out of range");
+  UBR_CHECK(d->S == 1 || d->S == 2, "ubr_wgrad: S unsupported");
+  int dymin = 127, dymax = -128, dxmin = 127, dxmax = -128;
+  for (int t = 0; t < d->ntaps; ++t) {
+    dymin = d->dy[t] < dymin ? d->dy[t] : dymin; dymax = d->dy[t] > dymax ? d->dy[t] : dymax;
+    dxmin = d->dx[t] < dxmin ? d->dx[t] : dxmin; dxmax = d->dx[t] > dxmax ? d->dx[t] : dxmax;
+  }
+  int TPG = d->ntaps <= 1 ? 1 : d->ntaps <= 4 ? 4 : d->ntaps <= 9 ? 9 : 25;
+  int MA = (d->Cout % 32 == 0) ? 2 : 1, NB = (d->Cin % 32 == 0) ? 2 : 1;
+  if (TPG == 25) { MA = 1; NB = 1; }
+  p->MA = MA; p->NB = NB; p->TPG = TPG;
+  p->TH = d->S == 1 ? 8 : 4;   // rows beyond GH are zero-filled, so small grids stay correct
+  p->HH = (p->TH - 1) * d->S + 1 + (dymax - dymin);
+  p->HW = 31 * d->S + 1 + (dxmax - dxmin);
+  p->pixbG = MA * 16 * esz + 16;
+  p->pixbX = NB * 16 * esz + 16;
+  size_t gbytes = (size_t)p->TH * 32 * p->pixbG;
+  gbytes = (gbytes + 15) & ~(size_t)15;
+  p->x_off = (int)gbytes;
+  size_t stage = gbytes + (size_t)p->HH * p->HW * p->pixbX;
+  size_t redb = (size_t)TPG * MA * NB * 4 * 64 * sizeof(float);
+  p->lds = stage > redb ? stage : redb;
+  UBR_CHECK(p->lds <= 160 * 1024, "ubr_wgrad: LDS need %zu exceeds 160 KiB", p->lds);
+  p->tiles_x = ubr_cdiv(d->GW, 32); p->tiles_y = ubr_cdiv(d->GH, p->TH);
+  p->ntiles = p->tiles_x * p->tiles_y * d->N;
+  p->gy = (d->Cout / (MA * 16)) * (d->Cin / (NB * 16));
+  p->gz = ubr_cdiv(d->ntaps, TPG);
+  int target = 1024 / (p->gy * p->gz);
+  if (target < 1) target = 1;
+  // bound slab memory: at most 64 MiB of partials per launch
+  const size_t slab_bytes = (size_t)d->ntaps * d->Cout * d->Cin * sizeof(float);
+  size_t cap = (64u << 20) / (slab_bytes ? slab_bytes : 1);
+  if (cap < 1) cap = 1;
+  if ((size_t)target > cap) target = (int)cap;
+  p->nsplit = p->ntiles < target ? p->ntiles : target;
+  return UBR_OK;
+}
+
+template <typename T, int MA, int NB, int TPG>
+int wlaunch(const WgK& k, const WPlan& p, hipStream_t st) {
+  auto fn = wgrad_kernel<T, MA, NB, TPG>;
+  if (p.lds > 64 * 1024) {
+    static thread_local size_t maxset = 0;
+    if (p.lds > maxset) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
+      if (e != hipSuccess) { ubr_set_error("ubr_wgrad: cannot raise LDS limit: %s", hipGetErrorString(e)); return UBR_ELAUNCH; }
+      maxset = p.lds;
+    }
+  }
+  hipLaunchKernelGGL(fn, dim3(p.nsplit, p.gy, p.gz), dim3(256), p.lds, st, k);
+  UBR_LAUNCH_CHECK("ubr_wgrad");
+  return UBR_OK;
+}
+
+template <typename T>
+int wdispatch(const WgK& k, const WPlan& p, hipStream_t st) {
+#define UBR_WCASE(ma, nb, tpg) if (p.MA == ma && p.NB == nb && p.TPG == tpg) return wlaunch<T, ma, nb, tpg>(k, p, st);
+  UBR_WCASE(1, 1, 1) UBR_WCASE(1, 2, 1) UBR_WCASE(2, 1, 1) UBR_WCASE(2, 2, 1)
+  UBR_WCASE(1, 1, 4) UBR_WCASE(1, 2, 4) UBR_WCASE(2, 1, 4) UBR_WCASE(2, 2, 4)
+  UBR_WCASE(1, 1, 9) UBR_WCASE(1, 2, 9) UBR_WCASE(2, 1, 9) UBR_WCASE(2, 2, 9)
+  UBR_WCASE(1, 1, 25)
+#undef UBR_WCASE
+  ubr_set_error("ubr_wgrad: no kernel for MA=%d NB=%d TPG=%d", p.MA, p.NB, p.TPG);
+  return UBR_EINVAL;
+}
+
+struct RedK {
+  const float* slabs; float* dst;
+  int nsplit, ntaps, Cout_pad, Cin, Cout_valid, Cin_valid, accumulate;
+  long sm, sk;
+  int tapidx[UBR_MAX_TAPS];
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedK k) {
+  const long per = (long)k.ntaps * k.Cout_pad * k.Cin;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per; i += (long)gridDim.x * 256) {
+    const int ci = (int)(i % k.Cin);
+    long r = i / k.Cin;
+    const int co = (int)(r % k.Cout_pad);
+    const int t = (int)(r / k.Cout_pad);
+    if (co >= k.Cout_valid || ci >= k.Cin_valid) continue;
+    float s = 0.f;
+    for (int sp = 0; sp < k.nsplit; ++sp) s += k.slabs[(long)sp * per + i];
+    float* d = k.dst + (long)co * k.sm + (long)ci * k.sk + k.tapidx[t];
+    *d = k.accumulate ? (*d + s) : s;
+  }
+}
+
+}  // namespace
+
+extern "C" int ubr_wgrad_plan(const ubr_wgrad_desc* d, int32_t* nsplit, int64_t* workspace_bytes) {
+  WPlan p{};
+  int rc = wgrad_plan(d, &p);
+  if (rc != UBR_OK) return rc;
+  if (nsplit) *nsplit = p.nsplit;
+  if (workspace_bytes) *workspace_bytes = (int64_t)p.nsplit * d->ntaps * d->Cout * d->Cin * (int64_t)sizeof(float);
+  return UBR_OK;
+}
+
+extern "C" int ubr_wgrad(const ubr_wgrad_desc* d, void* stream) {
+  WPlan p{};
+  int rc = wgrad_plan(d, &p);
+  if (rc != UBR_OK) return rc;
+  const int esz = ubr_esize(d->dtype);
+  UBR_CHECK(d->x.p && d->g.p && d->slabs, "ubr_wgrad: null tensor");
+  UBR_CHECK(d->nsplit == p.nsplit, "ubr_wgrad: nsplit %d does not match plan %d", d->nsplit, p.nsplit);
+  UBR_CHECK(ubr_aligned16(d->x.p) && ubr_aligned16(d->g.p), "ubr_wgrad: x/g must be 16-byte aligned");
+  UBR_CHECK((d->x.sx * esz) % 16 == 0 && (d->x.sy * esz) % 16 == 0 && (d->x.sn * esz) % 16 == 0 &&
+            (d->g.sx * esz) % 16 == 0 && (d->g.sy * esz) % 16 == 0 && (d->g.sn * esz) % 16 == 0,
+            "ubr_wgrad: strides must keep 16-byte alignment");
+  UBR_CHECK(d->x.sx >= d->Cin && d->g.sx >= d->Cout, "ubr_wgrad: pixel stride smaller than channel count");
+  const bool xf = d->xf.scale != nullptr;
+  UBR_CHECK(xf == (d->xf.shift != nullptr) && xf == (d->xf.lo != nullptr), "ubr_wgrad: xf needs scale, shift and lo together");
+  int dymin = 127, dxmin = 127;
+  for (int t = 0; t < d->ntaps; ++t) { dymin = d->dy[t] < dymin ? d->dy[t] : dymin; dxmin = d->dx[t] < dxmin ? d->dx[t] : dxmin; }
+  WgK k{};
+  k.x = (const char*)d->x.p; k.x_sn = d->x.sn * esz; k.x_sy = d->x.sy * esz; k.x_sx = d->x.sx * esz;
+  k.in_scale = d->xf.scale; k.in_shift = d->xf.shift; k.in_lo = d->xf.lo;
+  k.g = (const char*)d->g.p; k.g_sn = d->g.sn * esz; k.g_sy = d->g.sy * esz; k.g_sx = d->g.sx * esz;
+  k.slabs = d->slabs;
+  k.N = d->N; k.H = d->H; k.W = d->W; k.GH = d->GH; k.GW = d->GW; k.Cin = d->Cin; k.Cout_pad = d->Cout;
+  k.ntaps = d->ntaps; k.S = d->S; k.iy0 = d->iy0; k.ix0 = d->ix0; k.dymin = dymin; k.dxmin = dxmin; k.HH = p.HH; k.HW = p.HW;
+  k.TH = p.TH; k.tiles_x = p.tiles_x; k.tiles_y = p.tiles_y; k.ntiles = p.ntiles;
+  k.pixbG = p.pixbG; k.pixbX = p.pixbX; k.x_off = p.x_off;
+  k.n_cot = d->Cout / (p.MA * 16);
+  for (int t = 0; t < d->ntaps; ++t) { k.dy[t] = d->dy[t]; k.dx[t] = d->dx[t]; }
+  hipStream_t st = (hipStream_t)stream;
+  switch (d->dtype) {
+    case UBR_F32: return wdispatch<float>(k, p, st);
+    case UBR_BF16: return wdispatch<bf16_t>(k, p, st);
+    default: return wdispatch<f16_t>(k, p, st);
+  }
+}
+
+extern "C" int ubr_wgrad_reduce(const float* slabs, int nsplit, int ntaps, int Cout_pad, int Cin,
+                                int Cout_valid, int Cin_valid, float* dst, int64_t sm, int64_t sk,
+                                const int32_t* tapidx_host, int accumulate, void* stream) {
+  UBR_CHECK(slabs && dst && tapidx_host, "ubr_wgrad_reduce: null pointer");
+  UBR_CHECK(nsplit >= 1 && ntaps >= 1 && ntaps <= UBR_MAX_TAPS && Cout_pad > 0 && Cin > 0 &&
+            Cout_valid > 0 && Cout_valid <= Cout_pad && Cin_valid > 0 && Cin_valid <= Cin, "ubr_wgrad_reduce: bad extents");
+  RedK k{};
+  k.slabs = slabs; k.dst = dst; k.nsplit = nsplit; k.ntaps = ntaps; k.Cout_pad = Cout_pad; k.Cin = Cin;
+  k.Cout_valid = Cout_valid; k.Cin_valid = Cin_valid; k.accumulate = accumulate; k.sm = sm; k.sk = sk;
+  for (int t = 0; t < ntaps; ++t) k.tapidx[t] = tapidx_host[t];
+  const long per = (long)ntaps * Cout_pad * Cin;
+  int blocks = (int)((per + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, k);
+  UBR_LAUNCH_CHECK("ubr_wgrad_reduce");
+  return UBR_OK;
+}

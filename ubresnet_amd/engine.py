@@ -1,0 +1,493 @@
+"""Graph executor for the U-ResNet family: drives the HIP kernels for forward and backward.
+
+The reference expresses the network as torch.nn layer calls (models/ub_uresnet.py:88-147,
+models/common_layers.py:39-58,127-132) and leaves scheduling to autograd.  Here the module tree
+only OWNS parameters; this executor runs the fused schedule explicitly:
+
+  * NHWC activations; skip connections are written straight into the channel slice of the
+    decoder's concat buffer (torch.cat of models/common_layers.py:130 never materialises).
+  * train-mode BatchNorm: the producing conv accumulates sum/sum-of-squares in its epilogue,
+    a tiny finalize kernel makes (scale, shift), and the CONSUMER applies scale/shift/ReLU
+    while loading its operand -- conv -> BN -> ReLU costs one write and one read.
+  * backward is scheduled by hand in reverse order; parameter gradients land in one flat fp32
+    buffer laid out in completion order so data-parallel all-reduce can start per stage.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional
+
+import torch
+
+from . import _lib as L
+from . import ops
+from .ops import Affine
+
+T3 = ops.conv_taps(3, 1, 1)
+T1 = ops.conv_taps(1, 1, 0)
+T7 = ops.conv_taps(7, 1, 3)
+DG3 = ops.conv_dgrad_taps_s1(3, 1, 1)
+DG1 = ops.conv_dgrad_taps_s1(1, 1, 0)
+DG7 = ops.conv_dgrad_taps_s1(7, 1, 3)
+
+
+def _phase(t, ry, rx):
+    """stride-2 phase view of an NHWC tensor"""
+    return t[:, ry::2, rx::2, :]
+
+
+class BNSite:
+    """Per-BatchNorm2d runtime vectors (views into the per-pass workspaces)."""
+    __slots__ = ("mod", "C", "stats", "scale", "shift", "mean", "invstd", "red", "k1", "k2")
+
+    def __init__(self, mod):
+        self.mod = mod
+        self.C = mod.num_features
+
+
+class Saved:
+    """What one forward pass keeps for backward."""
+    pass
+
+
+class Engine:
+    def __init__(self, model, kind: str):
+        self.model = model
+        self.kind = kind  # "uresnet" | "aspp"
+        self._pack_cache: Dict[tuple, tuple] = {}
+        self._const: Dict[tuple, torch.Tensor] = {}
+        self.wws = ops.WgradWorkspace()
+        self.bn_sites: List[BNSite] = []
+        self._bn_of: Dict[int, BNSite] = {}
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                s = BNSite(m)
+                self.bn_sites.append(s)
+                self._bn_of[id(m)] = s
+        # gradient layout: parameters in the order their gradients complete in backward
+        self.grad_order = list(model._grad_completion_order())
+        self.grad_offsets = {}
+        off = 0
+        for name, p in self.grad_order:
+            self.grad_offsets[name] = off
+            off += (p.numel() + 3) // 4 * 4
+        self.grad_numel = off
+
+    # ------------------------------------------------------------------ helpers
+    def bn(self, mod) -> BNSite:
+        return self._bn_of[id(mod)]
+
+    def const(self, device, value: float, n: int) -> torch.Tensor:
+        key = (device, value)
+        t = self._const.get(key)
+        if t is None or t.numel() < n:
+            t = torch.full((max(n, 2048),), value, dtype=torch.float32, device=device)
+            self._const[key] = t
+        return t
+
+    def relu_affine(self, site: BNSite) -> Affine:
+        return Affine(site.scale, site.shift, self.const(site.scale.device, 0.0, site.C))
+
+    def packed(self, param: torch.Tensor, dtype, orient: str) -> torch.Tensor:
+        """cached packed image of a weight (repacked when the parameter changes)"""
+        key = (id(param), orient, dtype)
+        ver = (param._version, param.data_ptr())
+        hit = self._pack_cache.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        w = param.detach()
+        if not w.is_contiguous():
+            w = w.contiguous()
+        d0, d1, kh, kw = w.shape
+        kk = kh * kw
+        if orient == "fwd":        # Conv2d [Cout][Cin][k][k]: M=Cout, K=Cin
+            pk = ops.pack_weights(w, dtype, d0, d1, d1 * kk, kk, kk)
+        elif orient == "dgrad":    # M=Cin, K=Cout
+            pk = ops.pack_weights(w, dtype, d1, d0, kk, d1 * kk, kk)
+        elif orient == "tfwd":     # ConvTranspose2d [Cin][Cout][k][k] forward: M=Cout, K=Cin
+            pk = ops.pack_weights(w, dtype, d1, d0, kk, d1 * kk, kk)
+        elif orient == "tdgrad":   # ConvTranspose2d data gradient: M=Cin, K=Cout
+            pk = ops.pack_weights(w, dtype, d0, d1, d1 * kk, kk, kk)
+        else:
+            raise ValueError(orient)
+        self._pack_cache[key] = (ver, pk)
+        return pk
+
+    def _alloc_pass_workspaces(self, sv: Saved, device, training: bool):
+        nf = sum(4 * s.C for s in self.bn_sites)
+        sv.fws = torch.empty(nf, dtype=torch.float32, device=device)
+        off = 0
+        for s in self.bn_sites:
+            s.scale = sv.fws[off:off + s.C]; off += s.C
+            s.shift = sv.fws[off:off + s.C]; off += s.C
+            s.mean = sv.fws[off:off + s.C]; off += s.C
+            s.invstd = sv.fws[off:off + s.C]; off += s.C
+        sv.sites = [(s, s.scale, s.shift, s.mean, s.invstd) for s in self.bn_sites]
+        if training:
+            nd = sum(2 * s.C for s in self.bn_sites)
+            sv.dws = torch.empty(nd, dtype=torch.float64, device=device)
+            ops.zero_(sv.dws)
+            off = 0
+            for s in self.bn_sites:
+                s.stats = sv.dws[off:off + 2 * s.C]; off += 2 * s.C
+        else:
+            for s in self.bn_sites:
+                s.stats = None
+
+    def _rebind(self, sv: Saved):
+        """point the BN sites at the vectors of the pass that is being back-propagated"""
+        for s, scale, shift, mean, invstd in sv.sites:
+            s.scale, s.shift, s.mean, s.invstd = scale, shift, mean, invstd
+
+    def _finish_bn(self, site: BNSite, count: int, training: bool):
+        m = site.mod
+        if training:
+            mom = 0.1 if m.momentum is None else m.momentum
+            track = m.track_running_stats and m.running_mean is not None
+            ops.bn_finalize(site.stats, count, m.weight, m.bias, m.running_mean if track else None,
+                            m.running_var if track else None, m.num_batches_tracked if track else None,
+                            mom, m.eps, site.scale, site.shift, site.mean, site.invstd)
+        else:
+            ops.bn_eval_affine(m.weight, m.bias, m.running_mean, m.running_var, m.eps, site.scale, site.shift)
+
+    # ------------------------------------------------------------------ BasicBlock
+    def block_fwd(self, blk, x, out, training, dt):
+        """BasicBlock.forward (models/common_layers.py:39-58); x, out: NHWC views."""
+        N, H, W, Cin = x.shape
+        S = blk.stride
+        OH, OW = out.shape[1], out.shape[2]
+        Cout = out.shape[3]
+        dev = x.device
+        bn1, bn2 = self.bn(blk.bn1), self.bn(blk.bn2)
+        cnt = N * OH * OW
+        c1 = torch.empty((N, OH, OW, Cout), dtype=dt, device=dev)
+        ops.conv(x, self.packed(blk.conv1.weight, dt, "fwd"), c1, T3, Cout, S=S, stats=bn1.stats)
+        self._finish_bn(bn1, cnt, training)
+        c2 = torch.empty((N, OH, OW, Cout), dtype=dt, device=dev)
+        ops.conv(c1, self.packed(blk.conv2.weight, dt, "fwd"), c2, T3, Cout, xf=self.relu_affine(bn1), stats=bn2.stats)
+        self._finish_bn(bn2, cnt, training)
+        cb = None
+        if blk.bypass is not None:
+            bnb = self.bn(blk.bnpass)
+            cb = torch.empty((N, OH, OW, Cout), dtype=dt, device=dev)
+            ops.conv(x, self.packed(blk.bypass.weight, dt, "fwd"), cb, T1, Cout, S=S, stats=bnb.stats)
+            self._finish_bn(bnb, cnt, training)
+            ops.block_tail_fwd(c2, bn2.scale, bn2.shift, cb, bnb.scale, bnb.shift, out)
+        else:
+            ops.block_tail_fwd(c2, bn2.scale, bn2.shift, x, None, None, out)
+        if not self._save:
+            return None
+        rec = Saved()
+        rec.blk, rec.x, rec.c1, rec.c2, rec.cb, rec.out = blk, x, c1, c2, cb, out
+        return rec
+
+    def _bn_bwd(self, site: BNSite, ga, ga2, c, relu, G, cnt):
+        """backward through a = relu(bn(c)) (or bn only): returns g_c; writes dgamma/dbeta"""
+        red = torch.empty(2 * site.C, dtype=torch.float64, device=c.device)
+        ops.zero_(red)
+        ops.bn_bwd_reduce(ga, ga2, c, site.scale, site.shift, site.mean, site.invstd, relu, red)
+        k = torch.empty(2 * site.C, dtype=torch.float32, device=c.device)
+        k1, k2 = k[:site.C], k[site.C:]
+        ops.bn_bwd_finalize(red, cnt, site.C, G(site.mod.weight), G(site.mod.bias), False, k1, k2)
+        gc = torch.empty(c.shape, dtype=c.dtype, device=c.device)
+        ops.bn_bwd_apply(ga, ga2, c, site.scale, site.shift, site.mean, site.invstd, relu, k1, k2, gc)
+        return gc
+
+    def _conv_dgrad(self, conv_mod, g, gx, S, addend=None, k=3):
+        """data gradient of Conv2d(k, stride S, pad k//2): g (conv output grad) -> gx (input grad view)"""
+        dt = g.dtype
+        wp = self.packed(conv_mod.weight, dt, "dgrad")
+        Cin = gx.shape[3]
+        pad = k // 2
+        if S == 1:
+            taps = DG3 if k == 3 else (DG1 if k == 1 else DG7)
+            ops.conv(g, wp, gx, taps, Cin, addend=addend)
+        else:
+            for ry in range(2):
+                for rx in range(2):
+                    taps = ops.transposed_phase_taps(k, 1, pad, 2, ry, rx)
+                    if not taps:
+                        continue   # (1x1 stride-2: only phase (0,0) receives gradient; addend already in place)
+                    yv = _phase(gx, ry, rx)
+                    av = _phase(addend, ry, rx) if addend is not None else None
+                    ops.conv(g, wp, yv, taps, Cin, addend=av)
+
+    def block_bwd(self, rec, go, go2, G, need_gx=True):
+        """backward of BasicBlock; go (+go2): gradient wrt the block output. Returns g_x (or None)."""
+        blk, x, c1, c2, cb, out = rec.blk, rec.x, rec.c1, rec.c2, rec.cb, rec.out
+        dt, dev = c2.dtype, c2.device
+        N, OH, OW, Cout = c2.shape
+        cnt = N * OH * OW
+        S = blk.stride
+        bn1, bn2 = self.bn(blk.bn1), self.bn(blk.bn2)
+        byp = cb is not None
+        bnb = self.bn(blk.bnpass) if byp else None
+        nred = 4 if byp else 2
+        red = torch.empty(nred * Cout, dtype=torch.float64, device=dev)
+        ops.zero_(red)
+        red2 = red[:2 * Cout]
+        redb = red[2 * Cout:] if byp else None
+        ops.block_tail_bwd_reduce(go, go2, out, c2, bn2.scale, bn2.shift, bn2.mean, bn2.invstd,
+                                  cb, bnb.mean if byp else None, bnb.invstd if byp else None, red2, redb)
+        k = torch.empty(4 * Cout, dtype=torch.float32, device=dev)
+        ops.bn_bwd_finalize(red2, cnt, Cout, G(blk.bn2.weight), G(blk.bn2.bias), False, k[:Cout], k[Cout:2 * Cout])
+        if byp:
+            ops.bn_bwd_finalize(redb, cnt, Cout, G(blk.bnpass.weight), G(blk.bnpass.bias), False, k[2 * Cout:3 * Cout], k[3 * Cout:])
+        g_c2 = torch.empty(c2.shape, dtype=dt, device=dev)
+        g_sc = torch.empty(c2.shape, dtype=dt, device=dev)
+        ops.block_tail_bwd_apply(go, go2, out, c2, bn2.scale, bn2.shift, bn2.mean, bn2.invstd, k[:Cout], k[Cout:2 * Cout],
+                                 cb, bnb.scale if byp else None, bnb.mean if byp else None, bnb.invstd if byp else None,
+                                 k[2 * Cout:3 * Cout] if byp else None, k[3 * Cout:] if byp else None, g_c2, g_sc)
+        # conv2: weight grad (input = relu(bn1(c1)) re-formed on load) and data grad
+        kk = 9
+        ops.wgrad(c1, g_c2, T3, G(blk.conv2.weight), Cout * kk, kk, Cout, Cout, self.wws, xf=self.relu_affine(bn1))
+        g_a1 = torch.empty(c1.shape, dtype=dt, device=dev)
+        self._conv_dgrad(blk.conv2, g_c2, g_a1, 1)
+        del g_c2
+        g_c1 = self._bn_bwd(bn1, g_a1, None, c1, True, G, cnt)
+        del g_a1
+        Cin = x.shape[3]
+        ops.wgrad(x, g_c1, T3, G(blk.conv1.weight), Cin * kk, kk, Cout, Cin, self.wws, S=S)
+        if byp:
+            ops.wgrad(x, g_sc, T1, G(blk.bypass.weight), Cin, 1, Cout, Cin, self.wws, S=S)
+        if not need_gx:
+            return None
+        gx = torch.empty(x.shape, dtype=dt, device=dev)
+        if byp:
+            self._conv_dgrad(blk.conv1, g_c1, gx, S)
+            self._conv_dgrad(blk.bypass, g_sc, gx, S, addend=gx, k=1)
+        else:
+            self._conv_dgrad(blk.conv1, g_c1, gx, S, addend=g_sc)
+        return gx
+
+    # ------------------------------------------------------------------ DoubleResNet
+    def double_fwd(self, dbl, x, out, training, dt):
+        N, H, W, _ = x.shape
+        S = dbl.res1.stride
+        mid = torch.empty((N, out.shape[1], out.shape[2], out.shape[3]), dtype=dt, device=x.device)
+        r1 = self.block_fwd(dbl.res1, x, mid, training, dt)
+        r2 = self.block_fwd(dbl.res2, mid, out, training, dt)
+        return (r1, r2) if self._save else None
+
+    def double_bwd(self, recs, go, go2, G, need_gx=True):
+        r1, r2 = recs
+        g_mid = self.block_bwd(r2, go, go2, G)
+        return self.block_bwd(r1, g_mid, None, G, need_gx)
+
+    # ------------------------------------------------------------------ ConvTransposeLayer
+    def deconv_fwd(self, dl, x, cat, Cd, dt):
+        """ConvTranspose2d(k4,s2,p1) of x into channels [0,Cd) of the concat buffer (4 output phases)."""
+        wp = self.packed(dl.deconv.weight, dt, "tfwd")
+        up = cat[..., :Cd]
+        for ry in range(2):
+            for rx in range(2):
+                ops.conv(x, wp, _phase(up, ry, rx), ops.transposed_phase_taps(4, 1, 1, 2, ry, rx), Cd)
+
+    def declayer_fwd(self, dl, x, cat, Cd, out, training, dt):
+        """ConvTransposeLayer.forward (models/common_layers.py:127-132); the skip half of `cat` is already filled."""
+        self.deconv_fwd(dl, x, cat, Cd, dt)
+        recs = self.double_fwd(dl.res, cat, out, training, dt)
+        if not self._save:
+            return None
+        rec = Saved()
+        rec.dl, rec.x, rec.cat, rec.Cd, rec.recs = dl, x, cat, Cd, recs
+        return rec
+
+    def declayer_bwd(self, rec, go, G, xf_x: Optional[Affine] = None):
+        """returns (g_x, g_cat); g_cat[..., Cd:] is the gradient of the skip tensor"""
+        dl, x, cat, Cd = rec.dl, rec.x, rec.cat, rec.Cd
+        g_cat = self.double_bwd(rec.recs, go, None, G)
+        g_up = g_cat[..., :Cd]
+        Cin = x.shape[3]
+        dW = G(dl.deconv.weight)
+        for ry in range(2):
+            for rx in range(2):
+                taps = ops.transposed_phase_taps(4, 1, 1, 2, ry, rx)
+                ops.wgrad(x, _phase(g_up, ry, rx), taps, dW, 16, Cd * 16, Cd, Cin, self.wws, xf=xf_x)
+        # data gradient of the transposed conv = ordinary stride-2 conv over g_up
+        gx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+        wp = self.packed(dl.deconv.weight, x.dtype, "tdgrad")
+        ops.conv(g_up, wp, gx, ops.conv_taps(4, 1, 1), Cin, S=2)
+        return gx, g_cat
+
+    # ------------------------------------------------------------------ UResNet
+    def uresnet_forward(self, x: torch.Tensor, training: bool, dt: torch.dtype, save: bool):
+        """training: BatchNorm uses batch statistics (and updates running stats); save: keep activations for backward"""
+        m = self.model
+        self._save = save
+        if save and not training:
+            raise RuntimeError("ubresnet_amd: gradients through eval-mode BatchNorm are not supported; "
+                               "call model.train() or wrap inference in torch.no_grad()")
+        L.require_cuda(x, "input")
+        if x.dtype != torch.float32:
+            raise RuntimeError("ubresnet_amd: input must be float32 NCHW (got %s)" % x.dtype)
+        if x.dim() != 4 or x.shape[1] != m.conv1.in_channels:
+            raise RuntimeError("ubresnet_amd: expected input [B,%d,H,W], got %s" % (m.conv1.in_channels, tuple(x.shape)))
+        N, Cin, H, W = x.shape
+        if H % 32 or W % 32:
+            raise RuntimeError("ubresnet_amd: H and W must be multiples of 32 (ConvTranspose2d output_size contract of the "
+                               "reference, models/common_layers.py:128); got %dx%d" % (H, W))
+        if not x.is_contiguous():
+            x = x.contiguous()
+        dev = x.device
+        ip = m.inplanes
+        sv = Saved()
+        self._alloc_pass_workspaces(sv, dev, training)
+        E = lambda *shape: torch.empty(shape, dtype=dt, device=dev)
+
+        # stem: conv1 -> (bn1 + relu folded into consumers) -> pool ; x0 goes into dec1's concat buffer
+        bn1 = self.bn(m.bn1)
+        c0 = E(N, H, W, ip)
+        ops.stem_forward(x, m.conv1.weight, m.conv1.bias, c0, bn1.stats)
+        self._finish_bn(bn1, N * H * W, training)
+        cat1 = E(N, H, W, 2 * ip)
+        p0 = E(N, H // 2, W // 2, ip)
+        ops.maxpool_fwd(c0, self.relu_affine(bn1), p0, cat1[..., ip:], 2)
+
+        # encoder: each level's output is written into the skip half of the matching concat buffer
+        cat2 = E(N, H // 2, W // 2, 4 * ip)
+        cat3 = E(N, H // 4, W // 4, 8 * ip)
+        cat4 = E(N, H // 8, W // 8, 16 * ip)
+        cat5 = E(N, H // 16, W // 16, 32 * ip)
+        x5 = E(N, H // 32, W // 32, 32 * ip)
+        x1, x2, x3, x4 = cat2[..., 2 * ip:], cat3[..., 4 * ip:], cat4[..., 8 * ip:], cat5[..., 16 * ip:]
+        e1 = self.double_fwd(m.enc_layer1, p0, x1, training, dt)
+        e2 = self.double_fwd(m.enc_layer2, x1, x2, training, dt)
+        e3 = self.double_fwd(m.enc_layer3, x2, x3, training, dt)
+        e4 = self.double_fwd(m.enc_layer4, x3, x4, training, dt)
+        e5 = self.double_fwd(m.enc_layer5, x4, x5, training, dt)
+
+        d5o = E(N, H // 16, W // 16, 16 * ip)
+        d5 = self.declayer_fwd(m.dec_layer5, x5, cat5, 16 * ip, d5o, training, dt)
+        d4o = E(N, H // 8, W // 8, 8 * ip)
+        d4 = self.declayer_fwd(m.dec_layer4, d5o, cat4, 8 * ip, d4o, training, dt)
+        d3o = E(N, H // 4, W // 4, 4 * ip)
+        d3 = self.declayer_fwd(m.dec_layer3, d4o, cat3, 4 * ip, d3o, training, dt)
+        d2o = E(N, H // 2, W // 2, 2 * ip)
+        d2 = self.declayer_fwd(m.dec_layer2, d3o, cat2, 2 * ip, d2o, training, dt)
+        d1o = E(N, H, W, ip)
+        d1 = self.declayer_fwd(m.dec_layer1, d2o, cat1, ip, d1o, training, dt)
+
+        # head: conv10 + bias -> bn10 -> relu -> conv11 + bias -> log-softmax (fused epilogue, NCHW fp32)
+        bn10 = self.bn(m.bn10)
+        nk = m.conv10.out_channels
+        c10 = E(N, H, W, nk)
+        ops.conv(d1o, self.packed(m.conv10.weight, dt, "fwd"), c10, T7, nk, bias=m.conv10.bias, stats=bn10.stats)
+        self._finish_bn(bn10, N * H * W, training)
+        ncls = m.conv11.out_channels
+        out = torch.empty((N, ncls, H, W), dtype=torch.float32, device=dev)
+        ops.conv(c10, self.packed(m.conv11.weight, dt, "fwd"), out, T7, ncls, xf=self.relu_affine(bn10),
+                 bias=m.conv11.bias, logsoftmax=True)
+        if not save:
+            return out, None
+        sv.x, sv.c0, sv.cat1, sv.p0 = x, c0, cat1, p0
+        sv.enc = (e1, e2, e3, e4, e5)
+        sv.dec = (d1, d2, d3, d4, d5)
+        sv.cats = (cat1, cat2, cat3, cat4, cat5)
+        sv.d1o, sv.c10, sv.out, sv.dt = d1o, c10, out, dt
+        return out, sv
+
+    def uresnet_backward(self, sv: Saved, g_logp: torch.Tensor, grad_ready: Optional[Callable[[int, int], None]] = None):
+        """-> flat fp32 gradient buffer (layout self.grad_offsets)."""
+        m = self.model
+        dt = sv.dt
+        dev = sv.x.device
+        self._rebind(sv)
+        flat = torch.empty(self.grad_numel, dtype=torch.float32, device=dev)
+        views = {}
+        for name, p in self.grad_order:
+            o = self.grad_offsets[name]
+            views[id(p)] = flat[o:o + p.numel()].view(p.shape)
+        G = lambda p: views[id(p)]
+        done = [0]
+
+        def stage_done(last_param):
+            if grad_ready is None:
+                return
+            names = [n for n, _ in self.grad_order]
+            i = [id(p) for _, p in self.grad_order].index(id(last_param))
+            hi = self.grad_offsets[names[i]] + (self.grad_order[i][1].numel() + 3) // 4 * 4
+            if hi > done[0]:
+                grad_ready(done[0], hi)
+                done[0] = hi
+
+        N, ncls, H, W = sv.out.shape
+        ip = m.inplanes
+        if not g_logp.is_contiguous():
+            g_logp = g_logp.contiguous()
+        # ---- head ----
+        g_l = torch.empty((N, H, W, 16), dtype=dt, device=dev)
+        ops.logsoftmax_bwd(g_logp, sv.out, g_l)
+        bn10 = self.bn(m.bn10)
+        nk = m.conv10.out_channels
+        ops.wgrad(sv.c10, g_l, T7, G(m.conv11.weight), nk * 49, 49, ncls, nk, self.wws, xf=self.relu_affine(bn10))
+        red = torch.empty(16 + nk, dtype=torch.float64, device=dev)
+        ops.zero_(red)
+        ops.channel_sum(g_l, red[:16])
+        ops.cast_f64_to_f32(red[:16], G(m.conv11.bias), ncls)
+        g_a10 = torch.empty((N, H, W, nk), dtype=dt, device=dev)
+        # data gradient of conv11: K = the 16 (zero-padded) logit channels
+        wp = self._packed_dgrad_padded(m.conv11.weight, dt)
+        ops.conv(g_l, wp, g_a10, DG7, nk)
+        del g_l
+        g_c10 = self._bn_bwd(bn10, g_a10, None, sv.c10, True, G, N * H * W)
+        del g_a10
+        ops.wgrad(sv.d1o, g_c10, T7, G(m.conv10.weight), ip * 49, 49, nk, ip, self.wws)
+        ops.channel_sum(g_c10, red[16:])
+        ops.cast_f64_to_f32(red[16:], G(m.conv10.bias), nk)
+        g = torch.empty(sv.d1o.shape, dtype=dt, device=dev)
+        self._conv_dgrad(m.conv10, g_c10, g, 1, k=7)
+        del g_c10
+        stage_done(m.bn10.bias)
+        # ---- decoder ----
+        d1, d2, d3, d4, d5 = sv.dec
+        g, gc1 = self.declayer_bwd(d1, g, G); stage_done(m.dec_layer1.deconv.weight)
+        g, gc2 = self.declayer_bwd(d2, g, G); stage_done(m.dec_layer2.deconv.weight)
+        g, gc3 = self.declayer_bwd(d3, g, G); stage_done(m.dec_layer3.deconv.weight)
+        g, gc4 = self.declayer_bwd(d4, g, G); stage_done(m.dec_layer4.deconv.weight)
+        g, gc5 = self.declayer_bwd(d5, g, G); stage_done(m.dec_layer5.deconv.weight)
+        # ---- encoder (skip gradients arrive through the concat buffers' second halves) ----
+        e1, e2, e3, e4, e5 = sv.enc
+        g = self.double_bwd(e5, g, None, G); stage_done(m.enc_layer5.res1.conv1.weight)
+        g = self.double_bwd(e4, g, gc5[..., 16 * ip:], G); stage_done(m.enc_layer4.res1.conv1.weight)
+        g = self.double_bwd(e3, g, gc4[..., 8 * ip:], G); stage_done(m.enc_layer3.res1.conv1.weight)
+        g = self.double_bwd(e2, g, gc3[..., 4 * ip:], G); stage_done(m.enc_layer2.res1.conv1.weight)
+        g = self.double_bwd(e1, g, gc2[..., 2 * ip:], G); stage_done(m.enc_layer1.res1.conv1.weight)
+        # ---- stem ----
+        bn1 = self.bn(m.bn1)
+        g_x0 = torch.empty(sv.c0.shape, dtype=dt, device=dev)
+        ops.maxpool_bwd(sv.c0, self.relu_affine(bn1), g, gc1[..., ip:], g_x0, 2)
+        g_c0 = self._bn_bwd(bn1, g_x0, None, sv.c0, True, G, N * H * W)
+        ops.stem_wgrad(sv.x, g_c0, G(m.conv1.weight), G(m.conv1.bias), self.wws)
+        stage_done(self.grad_order[-1][1])
+        return flat, views
+
+    def _packed_dgrad_padded(self, w_param, dt):
+        """dgrad image of conv11: K (= num_classes) zero-padded to the 16 channels of g_logits"""
+        key = (id(w_param), "dgrad16", dt)
+        ver = (w_param._version, w_param.data_ptr())
+        hit = self._pack_cache.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        w = w_param.detach()
+        Cout, Cin, kh, kw = w.shape
+        kk = kh * kw
+        cpu = L.chans_per_unit(dt)
+        import ctypes as C
+        Mpad = (Cin + 15) // 16 * 16
+        dst = torch.empty((kk, 16 // cpu, Mpad, cpu), dtype=dt, device=w.device)
+        idx = (C.c_int32 * kk)(*range(kk))
+        L.check(L.lib().ubr_pack_weights(L.dtype_id(dt), w.data_ptr(), dst.data_ptr(), Cin, Mpad, Cout, 16, kk, Cin * kk, kk, idx,
+                                         L.stream_ptr()), "pack(conv11 dgrad)")
+        self._pack_cache[key] = (ver, dst)
+        return dst
+
+    # ------------------------------------------------------------------ dispatch
+    def forward(self, x, training, dt, save):
+        if self.kind == "uresnet":
+            return self.uresnet_forward(x, training, dt, save)
+        raise RuntimeError("ubresnet_amd: unknown network kind %r" % self.kind)
+
+    def backward(self, sv, g_out, grad_ready=None):
+        if self.kind == "uresnet":
+            return self.uresnet_backward(sv, g_out, grad_ready)
+        raise RuntimeError("ubresnet_amd: unknown network kind %r" % self.kind)

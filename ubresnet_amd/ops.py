@@ -1,0 +1,335 @@
+"""Operator layer: torch-tensor wrappers over the C ABI (include/ubresnet_hip.h).
+
+Activations are NHWC torch tensors (shape [N,H,W,C], stride(3)==1); channel slices of a concat
+buffer and stride-2 phase views are passed as ordinary torch views -- the kernels take explicit
+strides.  Nothing here computes on the host or falls back to torch ops.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+
+NEG_BIG = -3.0e38
+
+
+def _tv(t: Optional[torch.Tensor]) -> L.Tensor:
+    if t is None:
+        return L.Tensor(None, 0, 0, 0)
+    assert t.dim() == 4 and t.stride(3) == 1, "NHWC view with contiguous channels expected"
+    return L.Tensor(t.data_ptr(), t.stride(0), t.stride(1), t.stride(2))
+
+
+def _ps(t: torch.Tensor) -> int:
+    """pixel stride of a pixel-dense NHWC view (channel slices allowed)"""
+    n, h, w, c = t.shape
+    ps = t.stride(2)
+    if not (t.stride(3) == 1 and t.stride(1) == w * ps and (n == 1 or t.stride(0) == h * w * ps)):
+        raise RuntimeError("ubresnet_amd: expected a pixel-dense NHWC view, got shape %s strides %s" % (tuple(t.shape), t.stride()))
+    return ps
+
+
+class Affine:
+    """per-channel (scale, shift, lo) folded into a consumer's operand load"""
+    __slots__ = ("scale", "shift", "lo")
+
+    def __init__(self, scale, shift, lo):
+        self.scale, self.shift, self.lo = scale, shift, lo
+
+    def c(self) -> L.ChanAffine:
+        return L.ChanAffine(self.scale.data_ptr(), self.shift.data_ptr(), self.lo.data_ptr())
+
+
+def _xf(a: Optional[Affine]) -> L.ChanAffine:
+    return a.c() if a is not None else L.ChanAffine(None, None, None)
+
+
+# ------------------------------------------------------------------------------------------
+# tap geometry
+# ------------------------------------------------------------------------------------------
+def conv_taps(k: int, dil: int, pad: int) -> List[Tuple[int, int, int]]:
+    """nn.Conv2d forward taps: (dy, dx, weight tap index)"""
+    return [(ky * dil - pad, kx * dil - pad, ky * k + kx) for ky in range(k) for kx in range(k)]
+
+
+def conv_dgrad_taps_s1(k: int, dil: int, pad: int):
+    """data gradient of a stride-1 conv: gx[i] = sum_k gy[i + pad - k*dil] * W[k]"""
+    return [(pad - ky * dil, pad - kx * dil, ky * k + kx) for ky in range(k) for kx in range(k)]
+
+
+def transposed_phase_taps(k: int, dil: int, pad: int, s: int, ry: int, rx: int):
+    """taps of output phase (ry, rx) of a stride-s transposed conv (= dgrad of a stride-s conv, or
+    ConvTranspose2d forward): o = i*s - pad + k*dil  =>  i = (a*s + r + pad - k*dil)/s"""
+    out = []
+    for ky in range(k):
+        if (ry + pad - ky * dil) % s:
+            continue
+        for kx in range(k):
+            if (rx + pad - kx * dil) % s:
+                continue
+            out.append(((ry + pad - ky * dil) // s, (rx + pad - kx * dil) // s, ky * k + kx))
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+# conv / pack / wgrad
+# ------------------------------------------------------------------------------------------
+def pack_weights(src: torch.Tensor, dtype: torch.dtype, M: int, K: int, sm: int, sk: int, ntaps: int,
+                 tapidx: Optional[Sequence[int]] = None) -> torch.Tensor:
+    """-> packed image [ntaps][Kpad/CPU][Mpad][CPU] (see ubr_pack_weights)"""
+    L.require_cuda(src, "weights")
+    assert src.dtype == torch.float32 and src.is_contiguous()
+    cpu = L.chans_per_unit(dtype)
+    Mpad = (M + 15) // 16 * 16
+    Kpad = (K + cpu - 1) // cpu * cpu
+    dst = torch.empty((ntaps, Kpad // cpu, Mpad, cpu), dtype=dtype, device=src.device)
+    idx = (C.c_int32 * ntaps)(*(tapidx if tapidx is not None else range(ntaps)))
+    L.check(L.lib().ubr_pack_weights(L.dtype_id(dtype), src.data_ptr(), dst.data_ptr(), M, Mpad, K, Kpad, sm, sk, ntaps, idx,
+                                     L.stream_ptr()), "pack_weights")
+    return dst
+
+
+def conv(x: torch.Tensor, wp: torch.Tensor, y: torch.Tensor, taps, Cout: int, S: int = 1, iy0: int = 0, ix0: int = 0,
+         xf: Optional[Affine] = None, bias: Optional[torch.Tensor] = None, addend: Optional[torch.Tensor] = None,
+         stats: Optional[torch.Tensor] = None, logsoftmax: bool = False, tile_hint: int = 0, in_hw=None):
+    """One ubr_conv launch.  x: NHWC input view; y: NHWC output-grid view (or, with logsoftmax, the
+    contiguous fp32 NCHW result); taps: [(dy,dx,packed tap index)]."""
+    d = L.ConvDesc()
+    d.dtype = L.dtype_id(x.dtype)
+    N, H, W, Cin = x.shape
+    d.N, d.H, d.W, d.Cin = N, H, W, Cin
+    d.x = _tv(x)
+    d.xf = _xf(xf)
+    d.w = wp.data_ptr()
+    d.Cout, d.Cout_pad = Cout, wp.shape[2]
+    if wp.shape[1] * wp.shape[3] != Cin:
+        raise RuntimeError("conv: packed weights expect %d input channels, tensor has %d" % (wp.shape[1] * wp.shape[3], Cin))
+    d.ntaps = len(taps)
+    if not 1 <= len(taps) <= L.MAX_TAPS:
+        raise RuntimeError("conv: %d taps unsupported" % len(taps))
+    for i, (dy, dx, wt) in enumerate(taps):
+        d.dy[i], d.dx[i], d.wt[i] = dy, dx, wt
+        if wt >= wp.shape[0]:
+            raise RuntimeError("conv: tap index %d outside packed image" % wt)
+    d.S, d.iy0, d.ix0 = S, iy0, ix0
+    if logsoftmax:
+        assert y.dtype == torch.float32 and y.is_contiguous() and y.shape[1] == Cout
+        d.OH, d.OW = y.shape[2], y.shape[3]
+        d.y = L.Tensor(y.data_ptr(), 0, 0, 0)
+        d.epilogue = 1
+        if y.shape[0] != N:
+            raise RuntimeError("conv: batch mismatch")
+    else:
+        assert y.dtype == x.dtype
+        d.OH, d.OW = y.shape[1], y.shape[2]
+        d.y = _tv(y)
+        d.epilogue = 0
+        if y.shape[0] != N or y.shape[3] != Cout:
+            raise RuntimeError("conv: output view %s does not match N=%d Cout=%d" % (tuple(y.shape), N, Cout))
+    if addend is not None:
+        assert addend.shape == y.shape and addend.dtype == y.dtype
+        d.addend = _tv(addend)
+    d.bias = L.ptr(bias)
+    d.stats = L.ptr(stats)
+    if stats is not None:
+        assert stats.dtype == torch.float64 and stats.numel() >= 2 * Cout
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() >= Cout
+    if xf is not None:
+        assert xf.scale.numel() >= Cin
+    d.tile_hint = tile_hint
+    L.check(L.lib().ubr_conv(C.byref(d), L.stream_ptr()), "conv")
+
+
+class WgradWorkspace:
+    """grow-only fp32 slab workspace shared by all weight-gradient launches of a backward pass"""
+
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes: int, device) -> torch.Tensor:
+        n = (nbytes + 3) // 4
+        if self.buf is None or self.buf.numel() < n or self.buf.device != device:
+            self.buf = torch.empty(max(n, 1 << 20), dtype=torch.float32, device=device)
+        return self.buf
+
+
+def wgrad(x: torch.Tensor, g: torch.Tensor, taps, dst: torch.Tensor, sm: int, sk: int, Cout_valid: int, Cin_valid: int,
+          ws: WgradWorkspace, S: int = 1, iy0: int = 0, ix0: int = 0, xf: Optional[Affine] = None, accumulate: bool = False):
+    """dst[co*sm + ci*sk + tapidx] (+)= sum_pixels g[p][co] * xform(x)[p*S + tap][ci]
+    taps: [(dy, dx, tapidx into the PyTorch weight layout)]"""
+    d = L.WgradDesc()
+    d.dtype = L.dtype_id(x.dtype)
+    N, H, W, Cin = x.shape
+    d.N, d.H, d.W, d.Cin = N, H, W, Cin
+    d.x = _tv(x)
+    d.xf = _xf(xf)
+    assert g.dtype == x.dtype and g.shape[0] == N
+    d.GH, d.GW, d.Cout = g.shape[1], g.shape[2], g.shape[3]
+    d.g = _tv(g)
+    d.ntaps = len(taps)
+    for i, (dy, dx, _) in enumerate(taps):
+        d.dy[i], d.dx[i] = dy, dx
+    d.S, d.iy0, d.ix0 = S, iy0, ix0
+    nsplit, nbytes = C.c_int32(0), C.c_int64(0)
+    lib = L.lib()
+    L.check(lib.ubr_wgrad_plan(C.byref(d), C.byref(nsplit), C.byref(nbytes)), "wgrad_plan")
+    slabs = ws.get(nbytes.value, x.device)
+    d.slabs = slabs.data_ptr()
+    d.nsplit = nsplit.value
+    st = L.stream_ptr()
+    L.check(lib.ubr_wgrad(C.byref(d), st), "wgrad")
+    idx = (C.c_int32 * len(taps))(*[t[2] for t in taps])
+    assert dst.dtype == torch.float32
+    L.check(lib.ubr_wgrad_reduce(slabs.data_ptr(), nsplit.value, len(taps), d.Cout, Cin, Cout_valid, Cin_valid,
+                                 dst.data_ptr(), sm, sk, idx, 1 if accumulate else 0, st), "wgrad_reduce")
+
+
+# ------------------------------------------------------------------------------------------
+# stem
+# ------------------------------------------------------------------------------------------
+def stem_forward(x_nchw, weight, bias, y, stats):
+    L.require_cuda(x_nchw, "input image")
+    assert x_nchw.dtype == torch.float32 and x_nchw.is_contiguous()
+    N, Cin, H, W = x_nchw.shape
+    Cout = weight.shape[0]
+    assert weight.is_contiguous() and tuple(weight.shape) == (Cout, Cin, 7, 7)
+    L.check(L.lib().ubr_stem_forward(L.dtype_id(y.dtype), x_nchw.data_ptr(), N, Cin, H, W, weight.data_ptr(), L.ptr(bias), Cout,
+                                     _tv(y), L.ptr(stats), L.stream_ptr()), "stem_forward")
+
+
+def stem_wgrad(x_nchw, g, dweight, dbias, ws: WgradWorkspace, accumulate=False):
+    N, Cin, H, W = x_nchw.shape
+    Cout = g.shape[3]
+    lib = L.lib()
+    nbytes = lib.ubr_stem_wgrad_workspace(N, Cin, H, W, Cout)
+    part = ws.get(nbytes, g.device)
+    L.check(lib.ubr_stem_wgrad(L.dtype_id(g.dtype), x_nchw.data_ptr(), N, Cin, H, W, _tv(g), Cout, part.data_ptr(), nbytes,
+                               dweight.data_ptr(), L.ptr(dbias), 1 if accumulate else 0, L.stream_ptr()), "stem_wgrad")
+
+
+# ------------------------------------------------------------------------------------------
+# batch norm
+# ------------------------------------------------------------------------------------------
+def bn_finalize(stats, count, gamma, beta, rmean, rvar, nbt, momentum, eps, scale, shift, mean, invstd):
+    Cn = gamma.numel()
+    L.check(L.lib().ubr_bn_finalize(stats.data_ptr(), float(count), gamma.data_ptr(), beta.data_ptr(), L.ptr(rmean), L.ptr(rvar),
+                                    L.ptr(nbt), float(momentum), float(eps), Cn, scale.data_ptr(), shift.data_ptr(),
+                                    mean.data_ptr(), invstd.data_ptr(), L.stream_ptr()), "bn_finalize")
+
+
+def bn_eval_affine(gamma, beta, rmean, rvar, eps, scale, shift):
+    L.check(L.lib().ubr_bn_eval_affine(gamma.data_ptr(), beta.data_ptr(), rmean.data_ptr(), rvar.data_ptr(), float(eps),
+                                       gamma.numel(), scale.data_ptr(), shift.data_ptr(), L.stream_ptr()), "bn_eval_affine")
+
+
+def _npix(t):
+    return t.shape[0] * t.shape[1] * t.shape[2]
+
+
+def bn_bwd_reduce(ga, ga2, c, scale, shift, mean, invstd, relu, red):
+    L.check(L.lib().ubr_bn_bwd_reduce(L.dtype_id(c.dtype), _npix(c), c.shape[3], ga.data_ptr(), _ps(ga),
+                                      L.ptr(ga2), _ps(ga2) if ga2 is not None else 0, c.data_ptr(), _ps(c),
+                                      scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), 1 if relu else 0,
+                                      red.data_ptr(), L.stream_ptr()), "bn_bwd_reduce")
+
+
+def bn_bwd_finalize(red, count, Cn, dgamma, dbeta, accumulate, k1, k2):
+    L.check(L.lib().ubr_bn_bwd_finalize(red.data_ptr(), float(count), None, None, Cn, L.ptr(dgamma), L.ptr(dbeta),
+                                        1 if accumulate else 0, k1.data_ptr(), k2.data_ptr(), L.stream_ptr()), "bn_bwd_finalize")
+
+
+def bn_bwd_apply(ga, ga2, c, scale, shift, mean, invstd, relu, k1, k2, gc):
+    L.check(L.lib().ubr_bn_bwd_apply(L.dtype_id(c.dtype), _npix(c), c.shape[3], ga.data_ptr(), _ps(ga),
+                                     L.ptr(ga2), _ps(ga2) if ga2 is not None else 0, c.data_ptr(), _ps(c),
+                                     scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), 1 if relu else 0,
+                                     k1.data_ptr(), k2.data_ptr(), gc.data_ptr(), _ps(gc), L.stream_ptr()), "bn_bwd_apply")
+
+
+# ------------------------------------------------------------------------------------------
+# BasicBlock tail
+# ------------------------------------------------------------------------------------------
+def block_tail_fwd(c2, scale2, shift2, sc, scale_b, shift_b, out):
+    L.check(L.lib().ubr_block_tail_fwd(L.dtype_id(c2.dtype), _npix(c2), c2.shape[3], c2.data_ptr(), _ps(c2), scale2.data_ptr(),
+                                       shift2.data_ptr(), sc.data_ptr(), _ps(sc), L.ptr(scale_b), L.ptr(shift_b),
+                                       out.data_ptr(), _ps(out), L.stream_ptr()), "block_tail_fwd")
+
+
+def block_tail_bwd_reduce(go, go2, out, c2, scale2, shift2, mean2, invstd2, cb, mean_b, invstd_b, red2, red_b):
+    L.check(L.lib().ubr_block_tail_bwd_reduce(
+        L.dtype_id(c2.dtype), _npix(c2), c2.shape[3], go.data_ptr(), _ps(go), L.ptr(go2), _ps(go2) if go2 is not None else 0,
+        out.data_ptr(), _ps(out), c2.data_ptr(), _ps(c2), scale2.data_ptr(), shift2.data_ptr(), mean2.data_ptr(), invstd2.data_ptr(),
+        L.ptr(cb), _ps(cb) if cb is not None else 0, L.ptr(mean_b), L.ptr(invstd_b), red2.data_ptr(), L.ptr(red_b),
+        L.stream_ptr()), "block_tail_bwd_reduce")
+
+
+def block_tail_bwd_apply(go, go2, out, c2, scale2, shift2, mean2, invstd2, k1_2, k2_2,
+                         cb, scale_b, mean_b, invstd_b, k1_b, k2_b, g_c2, g_sc):
+    L.check(L.lib().ubr_block_tail_bwd_apply(
+        L.dtype_id(c2.dtype), _npix(c2), c2.shape[3], go.data_ptr(), _ps(go), L.ptr(go2), _ps(go2) if go2 is not None else 0,
+        out.data_ptr(), _ps(out), c2.data_ptr(), _ps(c2), scale2.data_ptr(), shift2.data_ptr(), mean2.data_ptr(), invstd2.data_ptr(),
+        k1_2.data_ptr(), k2_2.data_ptr(),
+        L.ptr(cb), _ps(cb) if cb is not None else 0, L.ptr(scale_b), L.ptr(mean_b), L.ptr(invstd_b), L.ptr(k1_b), L.ptr(k2_b),
+        g_c2.data_ptr(), _ps(g_c2), g_sc.data_ptr(), _ps(g_sc), L.stream_ptr()), "block_tail_bwd_apply")
+
+
+# ------------------------------------------------------------------------------------------
+# max pool
+# ------------------------------------------------------------------------------------------
+def maxpool_fwd(x, xf, pooled, xcopy, stride):
+    N, H, W, Cn = x.shape
+    L.check(L.lib().ubr_maxpool_fwd(L.dtype_id(x.dtype), N, H, W, Cn, stride, x.data_ptr(), _ps(x), _xf(xf),
+                                    pooled.data_ptr(), _ps(pooled), L.ptr(xcopy), _ps(xcopy) if xcopy is not None else 0,
+                                    L.stream_ptr()), "maxpool_fwd")
+
+
+def maxpool_bwd(x, xf, g_pooled, g_extra, gx, stride):
+    N, H, W, Cn = x.shape
+    L.check(L.lib().ubr_maxpool_bwd(L.dtype_id(x.dtype), N, H, W, Cn, stride, x.data_ptr(), _ps(x), _xf(xf),
+                                    g_pooled.data_ptr(), _ps(g_pooled), L.ptr(g_extra), _ps(g_extra) if g_extra is not None else 0,
+                                    gx.data_ptr(), _ps(gx), L.stream_ptr()), "maxpool_bwd")
+
+
+# ------------------------------------------------------------------------------------------
+# head / loss / misc
+# ------------------------------------------------------------------------------------------
+def logsoftmax_bwd(g_logp, logp, g_logits):
+    N, Cn, H, W = logp.shape
+    assert g_logp.is_contiguous() and logp.is_contiguous() and g_logp.dtype == torch.float32
+    L.check(L.lib().ubr_logsoftmax_bwd(L.dtype_id(g_logits.dtype), N, Cn, H, W, g_logp.data_ptr(), logp.data_ptr(),
+                                       g_logits.data_ptr(), _ps(g_logits), L.stream_ptr()), "logsoftmax_bwd")
+
+
+def pixelwise_nll_fwd(predict, target, pixelweights, classw, ignore_index, acc):
+    N, Cn, H, W = predict.shape
+    L.check(L.lib().ubr_pixelwise_nll_fwd(predict.data_ptr(), target.data_ptr(), pixelweights.data_ptr(), L.ptr(classw),
+                                          N, Cn, H, W, int(ignore_index), acc.data_ptr(), L.stream_ptr()), "pixelwise_nll_fwd")
+
+
+def pixelwise_nll_bwd(g_loss, target, pixelweights, classw, ignore_index, shape, g_predict):
+    N, Cn, H, W = shape
+    L.check(L.lib().ubr_pixelwise_nll_bwd(g_loss.data_ptr(), target.data_ptr(), pixelweights.data_ptr(), L.ptr(classw),
+                                          N, Cn, H, W, int(ignore_index), g_predict.data_ptr(), L.stream_ptr()), "pixelwise_nll_bwd")
+
+
+def confusion(logp, target, cm):
+    N, Cn, H, W = logp.shape
+    L.check(L.lib().ubr_confusion(logp.data_ptr(), target.data_ptr(), N, Cn, H, W, cm.data_ptr(), L.stream_ptr()), "confusion")
+
+
+def channel_sum(g, red):
+    L.check(L.lib().ubr_channel_sum(L.dtype_id(g.dtype), _npix(g), g.shape[3], g.data_ptr(), _ps(g), red.data_ptr(),
+                                    L.stream_ptr()), "channel_sum")
+
+
+def cast_f64_to_f32(src, dst, n, scale=1.0, accumulate=False):
+    L.check(L.lib().ubr_cast_f64_to_f32(src.data_ptr(), dst.data_ptr(), n, float(scale), 1 if accumulate else 0, L.stream_ptr()),
+            "cast_f64_to_f32")
+
+
+def zero_(t: torch.Tensor):
+    assert t.is_contiguous()
+    L.check(L.lib().ubr_zero(t.data_ptr(), t.numel() * t.element_size(), L.stream_ptr()), "zero")

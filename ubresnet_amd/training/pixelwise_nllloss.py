@@ -1,0 +1,80 @@
+"""PixelWiseNLLLoss with the reference's signature (training/pixelwise_nllloss.py:34-61), HIP kernels.
+
+    crit = PixelWiseNLLLoss(weight=None, size_average=True, ignore_index=-100)
+    loss = crit.forward(predict, target, pixelweights)      # or crit(...)
+
+predict: (b,c,h,w) float32 log-softmax; target: (b,h,w) int64; pixelweights: (b,h,w) float32.
+loss = mean over ALL b*h*w pixels of  -predict[b,target,h,w] * weight[target] * pixelweights
+(ignore_index pixels contribute zero but stay in the denominator, as the reference's
+reduce=False + torch.mean does, :51,:59).
+"""
+import os
+import sys
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if _ROOT not in sys.path:
+    sys.path.insert(0, _ROOT)
+
+import torch  # noqa: E402
+import torch.nn as nn  # noqa: E402
+
+from ubresnet_amd import _lib as L  # noqa: E402
+from ubresnet_amd import ops  # noqa: E402
+
+
+def _assert_no_grad(variable):
+    assert not variable.requires_grad, \
+        "nn criterions don't compute the gradient w.r.t. targets - please " \
+        "mark these variables as not requiring gradients"
+
+
+class _PixelNLLFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, predict, target, pixelweights, classw, ignore_index):
+        L.require_cuda(predict, "predict")
+        if predict.dtype != torch.float32 or pixelweights.dtype != torch.float32 or target.dtype != torch.int64:
+            raise RuntimeError("PixelWiseNLLLoss: expected predict/pixelweights float32 and target int64, got %s/%s/%s"
+                               % (predict.dtype, pixelweights.dtype, target.dtype))
+        if predict.dim() != 4 or tuple(target.shape) != (predict.shape[0], predict.shape[2], predict.shape[3]) \
+                or tuple(pixelweights.shape) != tuple(target.shape):
+            raise RuntimeError("PixelWiseNLLLoss: shape mismatch predict %s target %s pixelweights %s"
+                               % (tuple(predict.shape), tuple(target.shape), tuple(pixelweights.shape)))
+        predict, target, pixelweights = predict.contiguous(), target.contiguous(), pixelweights.contiguous()
+        acc = torch.empty(1, dtype=torch.float64, device=predict.device)
+        ops.zero_(acc)
+        ops.pixelwise_nll_fwd(predict, target, pixelweights, classw, ignore_index, acc)
+        loss = torch.empty((), dtype=torch.float32, device=predict.device)
+        ops.cast_f64_to_f32(acc, loss, 1, 1.0 / float(target.numel()))
+        ctx.save_for_backward(target, pixelweights)
+        ctx.classw, ctx.ignore_index, ctx.shape = classw, ignore_index, tuple(predict.shape)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        target, pixelweights = ctx.saved_tensors
+        g = torch.empty(ctx.shape, dtype=torch.float32, device=target.device)
+        g_loss = g_loss.contiguous().to(torch.float32)
+        ops.pixelwise_nll_bwd(g_loss, target, pixelweights, ctx.classw, ctx.ignore_index, ctx.shape, g)
+        return g, None, None, None, None
+
+
+class PixelWiseNLLLoss(nn.modules.loss._WeightedLoss):
+    def __init__(self, weight=None, size_average=True, ignore_index=-100):
+        # modern torch folds size_average into `reduction`; keep the attributes the reference reads (:51)
+        super(PixelWiseNLLLoss, self).__init__(weight, None, None, "mean")
+        self.size_average = size_average
+        self.ignore_index = ignore_index
+        self.reduce = False
+
+    def forward(self, predict, target, pixelweights):
+        """
+        predict: (b,c,h,w) tensor with output from logsoftmax
+        target:  (b,h,w) tensor with correct class
+        pixelweights: (b,h,w) tensor with weights for each pixel
+        """
+        _assert_no_grad(target)
+        _assert_no_grad(pixelweights)
+        classw = self.weight
+        if classw is not None:
+            classw = classw.to(device=predict.device, dtype=torch.float32).contiguous()
+        return _PixelNLLFn.apply(predict, target, pixelweights, classw, self.ignore_index)
