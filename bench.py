@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of one full U-ResNet train step (forward + PixelWiseNLLLoss +
+backward + Adam) on synthetic 512x512 LArTPC crops, data-parallel over N MI355X.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+BASELINE.json configs[1]: ub_uresnet 3-class, bf16 storage / fp32 accumulate, batch 16 per GPU,
+512x512x1 -> 3 classes.  Weak scaling: per-GPU batch fixed, global batch = 16*N; the only
+exchange is the RCCL gradient all-reduce, overlapped with backward (ubresnet_amd/dist.py).
+Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel, timed
+live with HIP events on the launch stream) and `cpu_baseline` (the CPU oracle, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+MODEL_BYTES_PER_IMG_BF16 = 1.50e9   # SURVEY.md section 8d "fused-min v1": train step, bf16
+MODEL_FLOP_PER_IMG = 199.8e9
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--inplanes", type=int, default=16)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-breakdown", action="store_true")
+    ap.add_argument("--breakdown-file", default="")
+    return ap.parse_args()
+
+
+def cpu_baseline(size, inplanes, seconds_budget=25.0):
+    """The CPU oracle (validated against the reference's own code, tests/test_oracle_golden.py)
+    doing the same train step on the host cores: BASELINE config 0 (batch 2, fp32)."""
+    from collections import OrderedDict
+    from oracle import uresnet_oracle as O
+    from ubresnet_amd import synthetic
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    B = 2
+    sd = O.seeded_state_dict(O.uresnet_schema(3, 1, inplanes, 16), 42)
+    x, lab, wgt = synthetic.make_batch(B, size, size, 1000)
+    xt, lt, wt = torch.from_numpy(x), torch.from_numpy(lab), torch.from_numpy(wgt)
+    p = OrderedDict((k, (v.clone().requires_grad_(True) if O.is_param_key(k) else v.clone())) for k, v in sd.items())
+    opt = torch.optim.Adam([v for k, v in p.items() if O.is_param_key(k)], lr=1e-5, weight_decay=1e-4)
+
+    def step():
+        ns = {}
+        logp = O.uresnet_forward(p, xt, True, ns)
+        loss = O.pixelwise_nll(logp, lt, wt)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        for k, v in ns.items():
+            p[k] = v
+        return float(loss)
+
+    step()
+    t0 = time.time()
+    n = 0
+    while True:
+        step()
+        n += 1
+        el = time.time() - t0
+        if el > seconds_budget or n >= 12:
+            break
+    return {"value": B * n / el, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "%d timed train steps (1 warm-up) of the CPU oracle, UResNet ip%d fp32, batch %d, %dx%d, Adam" % (n, inplanes, B, size, size),
+            "ms_per_step": 1e3 * el / n}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    elif a.gpus != 1:
+        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    dev = torch.device("cuda", local if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    from ubresnet_amd import ops, synthetic
+    from ubresnet_amd.dist import GradAllReducer, shard_range
+    from ubresnet_amd.models.ub_uresnet import UResNet
+    from ubresnet_amd.training.pixelwise_nllloss import PixelWiseNLLLoss
+
+    dt = {"bf16": torch.bfloat16, "f32": torch.float32, "f16": torch.float16}[a.dtype]
+    torch.manual_seed(1234)                     # identical initial weights on every rank (DP replicas)
+    model = UResNet(num_classes=3, input_channels=1, inplanes=a.inplanes).to(dev)
+    model.compute_dtype = dt
+    model.train()
+    crit = PixelWiseNLLLoss()
+    params = [p for p in model.parameters()]
+    try:
+        opt = torch.optim.Adam(params, lr=1e-5, weight_decay=1e-4, fused=True)   # reference: Adam(lr 1e-5, wd 1e-4), wlarcv2.py:155-157
+    except Exception:
+        opt = torch.optim.Adam(params, lr=1e-5, weight_decay=1e-4)
+    reducer = GradAllReducer(model) if world > 1 else None
+
+    # synthetic crops: rank r holds images [r*b, (r+1)*b) of the global batch, resident in HBM
+    gb = a.batch * world
+    lo, hi = shard_range(gb, rank, world)
+    x, lab, wgt = synthetic.make_batch(a.batch, a.size, a.size, seed0=1000 + lo)
+    x, lab, wgt = torch.from_numpy(x).to(dev), torch.from_numpy(lab).to(dev), torch.from_numpy(wgt).to(dev)
+
+    def step():
+        out = model.forward(x)
+        loss = crit.forward(out, lab, wgt)
+        opt.zero_grad()
+        loss.backward()
+        if reducer is not None:
+            reducer.finish()
+        opt.step()
+        return loss
+
+    for _ in range(a.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    lossv = float(loss.item())
+
+    res = {
+        "metric": "images/sec, 512x512 U-ResNet train step (fwd+loss+bwd+Adam)",
+        "value": gb * a.steps / el, "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": 1e3 * el / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": a.dtype, "data": "synthetic",
+        "config": {"workload": "ub_uresnet 3-class ip%d %s, batch %d per GPU (global %d), %dx%dx1 synthetic LArTPC crops, Adam(1e-5, wd 1e-4)"
+                               % (a.inplanes, a.dtype, a.batch, gb, a.size, a.size),
+                   "parallelism": "dp%d" % world, "global_batch": gb},
+        "final_loss": lossv,
+    }
+    esz = 4 if a.dtype == "f32" else 2
+    per_img = MODEL_BYTES_PER_IMG_BF16 * (esz / 2.0) * (a.size * a.size / 262144.0) * (a.inplanes / 16.0)
+    res["step_model"] = {"algorithmic_bytes_per_image": per_img, "achieved_GBs_per_gpu": per_img * a.batch * a.steps / el / 1e9,
+                         "frac_of_hbm_peak": per_img * a.batch * a.steps / el / 1e9 / HBM_PEAK_GBS,
+                         "achieved_TFLOPs_per_gpu": MODEL_FLOP_PER_IMG * (a.size * a.size / 262144.0) * a.batch * a.steps / el / 1e12}
+
+    # ---- per-launch breakdown of one more step (HIP events on the launch stream) -> roofline of the dominant kernel
+    if rank == 0 and not a.no_breakdown:
+        prof = ops.LaunchProfiler()
+        ops._prof = prof
+        step()
+        ops._prof = None
+        agg = prof.summary()
+        rows = sorted(((v[1], k, v) for k, v in agg.items()), reverse=True)
+        tot = sum(r[0] for r in rows)
+        (tsum, (name, sig), (cnt, _, nbytes)) = rows[0]
+        ach = nbytes / tsum / 1e9
+        res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                           "traffic": None, "kernel": name, "shape": sig, "launches_per_step": cnt,
+                           "avg_launch_ms": 1e3 * tsum / cnt, "algorithmic_bytes_per_launch": nbytes / cnt,
+                           "share_of_gpu_time": tsum / tot}
+        res["kernel_time_ms_per_step"] = 1e3 * tot
+        if a.breakdown_file:
+            with open(a.breakdown_file, "w") as f:
+                f.write("%-22s %-58s %5s %10s %9s %8s\n" % ("op", "shape", "n", "total_ms", "GB/s", "share"))
+                for tsum_, (nm, sg), (c_, _, nb_) in rows:
+                    f.write("%-22s %-58s %5d %10.3f %9.1f %7.1f%%\n" % (nm, sg, c_, 1e3 * tsum_, nb_ / max(tsum_, 1e-12) / 1e9, 100 * tsum_ / tot))
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(a.size, a.inplanes)
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,83 @@
+"""Data-parallel gradient exchange: one process per GPU, RCCL all-reduce over xGMI.
+
+The reference's multi-GPU mode is single-process nn.DataParallel
+(training/train_ubresnet2018_wlarcv2.py:99,103): per step it broadcasts all parameters,
+scatters the batch, gathers the outputs and reduce-adds 165 gradient tensors onto device 0,
+with BatchNorm statistics local to each replica.  Here parameters stay replicated, each rank
+trains on its own shard of the global batch (local BatchNorm statistics, the same semantics),
+and the ONLY exchange is an averaged all-reduce of the flat gradient buffer.  The graph
+executor reports contiguous gradient ranges as backward completes them (decoder/head first),
+so buckets are reduced on a side stream while the encoder's backward is still running.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+class GradAllReducer:
+    def __init__(self, model, bucket_bytes: int = 16 << 20, group=None):
+        self.model = model
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.bucket_elems = max(1, bucket_bytes // 4)
+        self.stream = None
+        self.pending_lo = None
+        self.pending_hi = None
+        self.flat = None
+        self.works = []
+        self.use_avg = dist.is_initialized() and dist.get_backend(group) == "nccl"
+        model._grad_ready_hook = self._hook
+
+    # called by the executor on the compute stream: flat[lo:hi] is final
+    def _hook(self, flat: torch.Tensor, lo: int, hi: int):
+        if self.world == 1:
+            return
+        if self.flat is not flat:
+            self.flat, self.pending_lo, self.pending_hi = flat, lo, lo
+        self.pending_hi = hi
+        last = hi >= flat.numel()
+        if self.pending_hi - self.pending_lo >= self.bucket_elems or last:
+            self._launch(self.pending_lo, self.pending_hi)
+            self.pending_lo = self.pending_hi
+
+    def _launch(self, lo: int, hi: int):
+        if hi <= lo:
+            return
+        chunk = self.flat[lo:hi]
+        op = dist.ReduceOp.AVG if self.use_avg else dist.ReduceOp.SUM
+        if chunk.is_cuda:
+            if self.stream is None:
+                self.stream = torch.cuda.Stream(device=chunk.device)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(chunk.device))
+            with torch.cuda.stream(self.stream):
+                self.stream.wait_event(ev)
+                self.works.append(dist.all_reduce(chunk, op=op, group=self.group, async_op=True))
+        else:
+            self.works.append(dist.all_reduce(chunk, op=op, group=self.group, async_op=True))
+
+    def finish(self):
+        """make the compute stream wait for every outstanding bucket (call before optimizer.step)"""
+        if self.world == 1 or self.flat is None:
+            return
+        if self.pending_hi is not None and self.pending_hi > self.pending_lo:
+            self._launch(self.pending_lo, self.pending_hi)
+            self.pending_lo = self.pending_hi
+        for w in self.works:
+            w.wait()
+        self.works = []
+        if self.flat.is_cuda and self.stream is not None:
+            torch.cuda.current_stream(self.flat.device).wait_stream(self.stream)
+        if not self.use_avg:
+            self.flat.div_(self.world)
+        self.flat = None
+
+
+def shard_range(global_batch: int, rank: int, world: int):
+    """rank r takes images [r*b, (r+1)*b) of the global batch (equal shards => mean of rank means
+    equals the global-mean loss PixelWiseNLLLoss computes, training/pixelwise_nllloss.py:59)"""
+    if global_batch % world:
+        raise ValueError("global batch %d is not divisible by world size %d" % (global_batch, world))
+    b = global_batch // world
+    return rank * b, (rank + 1) * b

@@ -386,7 +386,7 @@ class Engine:
         sv.d1o, sv.c10, sv.out, sv.dt = d1o, c10, out, dt
         return out, sv
 
-    def uresnet_backward(self, sv: Saved, g_logp: torch.Tensor, grad_ready: Optional[Callable[[int, int], None]] = None):
+    def uresnet_backward(self, sv: Saved, g_logp: torch.Tensor, grad_ready: Optional[Callable] = None):
         """-> flat fp32 gradient buffer (layout self.grad_offsets)."""
         m = self.model
         dt = sv.dt
@@ -407,7 +407,7 @@ class Engine:
             i = [id(p) for _, p in self.grad_order].index(id(last_param))
             hi = self.grad_offsets[names[i]] + (self.grad_order[i][1].numel() + 3) // 4 * 4
             if hi > done[0]:
-                grad_ready(done[0], hi)
+                grad_ready(flat, done[0], hi)
                 done[0] = hi
 
         N, ncls, H, W = sv.out.shape

@@ -15,6 +15,60 @@ from . import _lib as L
 
 NEG_BIG = -3.0e38
 
+# Optional per-launch timing (bench.py's kernel breakdown): when set, every wrapped op records a
+# torch.cuda.Event pair on the current stream (the stream the kernels are launched on).
+_prof = None
+
+
+class LaunchProfiler:
+    """collects (op, shape signature, algorithmic bytes, start/end events) per C-ABI launch"""
+
+    def __init__(self):
+        self.records = []
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, sig, nbytes, e0, e1 in self.records:
+            k = (name, sig)
+            a = agg.setdefault(k, [0, 0.0, 0])
+            a[0] += 1
+            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[2] += nbytes
+        return agg
+
+
+def _act_bytes(args):
+    n = 0
+    for a in args:
+        if isinstance(a, torch.Tensor) and a.dim() == 4:
+            n += a.numel() * a.element_size()
+    return n
+
+
+def _timed(name):
+    def deco(fn):
+        def wrapper(*args, **kwargs):
+            if _prof is None:
+                return fn(*args, **kwargs)
+            acts = [a for a in list(args) + list(kwargs.values()) if isinstance(a, torch.Tensor) and a.dim() == 4]
+            sig = " ".join("x".join(map(str, a.shape)) for a in acts[:3])
+            taps = kwargs.get("taps", args[3] if name in ("conv",) and len(args) > 3 else (args[2] if name == "wgrad" and len(args) > 2 else None))
+            if isinstance(taps, (list, tuple)):
+                sig += " taps%d" % len(taps)
+            if "S" in kwargs:
+                sig += " S%d" % kwargs["S"]
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*args, **kwargs)
+            e1.record()
+            _prof.records.append((name, sig, _act_bytes(acts), e0, e1))
+            return r
+        wrapper.__name__ = fn.__name__
+        wrapper.__doc__ = fn.__doc__
+        return wrapper
+    return deco
+
 
 def _tv(t: Optional[torch.Tensor]) -> L.Tensor:
     if t is None:
@@ -77,6 +131,7 @@ def transposed_phase_taps(k: int, dil: int, pad: int, s: int, ry: int, rx: int):
 # ------------------------------------------------------------------------------------------
 # conv / pack / wgrad
 # ------------------------------------------------------------------------------------------
+@_timed("pack_weights")
 def pack_weights(src: torch.Tensor, dtype: torch.dtype, M: int, K: int, sm: int, sk: int, ntaps: int,
                  tapidx: Optional[Sequence[int]] = None) -> torch.Tensor:
     """-> packed image [ntaps][Kpad/CPU][Mpad][CPU] (see ubr_pack_weights)"""
@@ -92,6 +147,7 @@ def pack_weights(src: torch.Tensor, dtype: torch.dtype, M: int, K: int, sm: int,
     return dst
 
 
+@_timed("conv")
 def conv(x: torch.Tensor, wp: torch.Tensor, y: torch.Tensor, taps, Cout: int, S: int = 1, iy0: int = 0, ix0: int = 0,
          xf: Optional[Affine] = None, bias: Optional[torch.Tensor] = None, addend: Optional[torch.Tensor] = None,
          stats: Optional[torch.Tensor] = None, logsoftmax: bool = False, tile_hint: int = 0, in_hw=None):
@@ -157,6 +213,7 @@ class WgradWorkspace:
         return self.buf
 
 
+@_timed("wgrad")
 def wgrad(x: torch.Tensor, g: torch.Tensor, taps, dst: torch.Tensor, sm: int, sk: int, Cout_valid: int, Cin_valid: int,
           ws: WgradWorkspace, S: int = 1, iy0: int = 0, ix0: int = 0, xf: Optional[Affine] = None, accumulate: bool = False):
     """dst[co*sm + ci*sk + tapidx] (+)= sum_pixels g[p][co] * xform(x)[p*S + tap][ci]
@@ -191,6 +248,7 @@ def wgrad(x: torch.Tensor, g: torch.Tensor, taps, dst: torch.Tensor, sm: int, sk
 # ------------------------------------------------------------------------------------------
 # stem
 # ------------------------------------------------------------------------------------------
+@_timed("stem_forward")
 def stem_forward(x_nchw, weight, bias, y, stats):
     L.require_cuda(x_nchw, "input image")
     assert x_nchw.dtype == torch.float32 and x_nchw.is_contiguous()
@@ -201,6 +259,7 @@ def stem_forward(x_nchw, weight, bias, y, stats):
                                      _tv(y), L.ptr(stats), L.stream_ptr()), "stem_forward")
 
 
+@_timed("stem_wgrad")
 def stem_wgrad(x_nchw, g, dweight, dbias, ws: WgradWorkspace, accumulate=False):
     N, Cin, H, W = x_nchw.shape
     Cout = g.shape[3]
@@ -230,6 +289,7 @@ def _npix(t):
     return t.shape[0] * t.shape[1] * t.shape[2]
 
 
+@_timed("bn_bwd_reduce")
 def bn_bwd_reduce(ga, ga2, c, scale, shift, mean, invstd, relu, red):
     L.check(L.lib().ubr_bn_bwd_reduce(L.dtype_id(c.dtype), _npix(c), c.shape[3], ga.data_ptr(), _ps(ga),
                                       L.ptr(ga2), _ps(ga2) if ga2 is not None else 0, c.data_ptr(), _ps(c),
@@ -242,6 +302,7 @@ def bn_bwd_finalize(red, count, Cn, dgamma, dbeta, accumulate, k1, k2):
                                         1 if accumulate else 0, k1.data_ptr(), k2.data_ptr(), L.stream_ptr()), "bn_bwd_finalize")
 
 
+@_timed("bn_bwd_apply")
 def bn_bwd_apply(ga, ga2, c, scale, shift, mean, invstd, relu, k1, k2, gc):
     L.check(L.lib().ubr_bn_bwd_apply(L.dtype_id(c.dtype), _npix(c), c.shape[3], ga.data_ptr(), _ps(ga),
                                      L.ptr(ga2), _ps(ga2) if ga2 is not None else 0, c.data_ptr(), _ps(c),
@@ -252,12 +313,14 @@ def bn_bwd_apply(ga, ga2, c, scale, shift, mean, invstd, relu, k1, k2, gc):
 # ------------------------------------------------------------------------------------------
 # BasicBlock tail
 # ------------------------------------------------------------------------------------------
+@_timed("block_tail_fwd")
 def block_tail_fwd(c2, scale2, shift2, sc, scale_b, shift_b, out):
     L.check(L.lib().ubr_block_tail_fwd(L.dtype_id(c2.dtype), _npix(c2), c2.shape[3], c2.data_ptr(), _ps(c2), scale2.data_ptr(),
                                        shift2.data_ptr(), sc.data_ptr(), _ps(sc), L.ptr(scale_b), L.ptr(shift_b),
                                        out.data_ptr(), _ps(out), L.stream_ptr()), "block_tail_fwd")
 
 
+@_timed("block_tail_bwd_reduce")
 def block_tail_bwd_reduce(go, go2, out, c2, scale2, shift2, mean2, invstd2, cb, mean_b, invstd_b, red2, red_b):
     L.check(L.lib().ubr_block_tail_bwd_reduce(
         L.dtype_id(c2.dtype), _npix(c2), c2.shape[3], go.data_ptr(), _ps(go), L.ptr(go2), _ps(go2) if go2 is not None else 0,
@@ -266,6 +329,7 @@ def block_tail_bwd_reduce(go, go2, out, c2, scale2, shift2, mean2, invstd2, cb, 
         L.stream_ptr()), "block_tail_bwd_reduce")
 
 
+@_timed("block_tail_bwd_apply")
 def block_tail_bwd_apply(go, go2, out, c2, scale2, shift2, mean2, invstd2, k1_2, k2_2,
                          cb, scale_b, mean_b, invstd_b, k1_b, k2_b, g_c2, g_sc):
     L.check(L.lib().ubr_block_tail_bwd_apply(
@@ -279,6 +343,7 @@ def block_tail_bwd_apply(go, go2, out, c2, scale2, shift2, mean2, invstd2, k1_2,
 # ------------------------------------------------------------------------------------------
 # max pool
 # ------------------------------------------------------------------------------------------
+@_timed("maxpool_fwd")
 def maxpool_fwd(x, xf, pooled, xcopy, stride):
     N, H, W, Cn = x.shape
     L.check(L.lib().ubr_maxpool_fwd(L.dtype_id(x.dtype), N, H, W, Cn, stride, x.data_ptr(), _ps(x), _xf(xf),
@@ -286,6 +351,7 @@ def maxpool_fwd(x, xf, pooled, xcopy, stride):
                                     L.stream_ptr()), "maxpool_fwd")
 
 
+@_timed("maxpool_bwd")
 def maxpool_bwd(x, xf, g_pooled, g_extra, gx, stride):
     N, H, W, Cn = x.shape
     L.check(L.lib().ubr_maxpool_bwd(L.dtype_id(x.dtype), N, H, W, Cn, stride, x.data_ptr(), _ps(x), _xf(xf),
@@ -296,6 +362,7 @@ def maxpool_bwd(x, xf, g_pooled, g_extra, gx, stride):
 # ------------------------------------------------------------------------------------------
 # head / loss / misc
 # ------------------------------------------------------------------------------------------
+@_timed("logsoftmax_bwd")
 def logsoftmax_bwd(g_logp, logp, g_logits):
     N, Cn, H, W = logp.shape
     assert g_logp.is_contiguous() and logp.is_contiguous() and g_logp.dtype == torch.float32
@@ -320,6 +387,7 @@ def confusion(logp, target, cm):
     L.check(L.lib().ubr_confusion(logp.data_ptr(), target.data_ptr(), N, Cn, H, W, cm.data_ptr(), L.stream_ptr()), "confusion")
 
 
+@_timed("channel_sum")
 def channel_sum(g, red):
     L.check(L.lib().ubr_channel_sum(L.dtype_id(g.dtype), _npix(g), g.shape[3], g.data_ptr(), _ps(g), red.data_ptr(),
                                     L.stream_ptr()), "channel_sum")
