@@ -45,17 +45,29 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(size, inplanes, seconds_budget=25.0):
+def host_cores():
+    """threads the CPU baseline may use: affinity, capped by the cgroup CPU quota of the box"""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(per))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("UBR_CPU_THREADS", "16"))))
+
+
+def cpu_baseline(size, inplanes, seconds_budget=20.0):
     """The CPU oracle (validated against the reference's own code, tests/test_oracle_golden.py)
     doing the same train step on the host cores: BASELINE config 0 (batch 2, fp32)."""
     from collections import OrderedDict
     from oracle import uresnet_oracle as O
     from ubresnet_amd import synthetic
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = host_cores()
     torch.set_num_threads(cores)
     B = 2
     sd = O.seeded_state_dict(O.uresnet_schema(3, 1, inplanes, 16), 42)
@@ -73,17 +85,18 @@ def cpu_baseline(size, inplanes, seconds_budget=25.0):
         opt.step()
         for k, v in ns.items():
             p[k] = v
-        return float(loss)
+        return float(loss.detach())
 
+    tw = time.time()
     step()
+    tw = time.time() - tw
+    nmax = max(1, min(12, int(seconds_budget / max(tw, 1e-3))))
     t0 = time.time()
     n = 0
-    while True:
+    while n < nmax:
         step()
         n += 1
-        el = time.time() - t0
-        if el > seconds_budget or n >= 12:
-            break
+    el = time.time() - t0
     return {"value": B * n / el, "unit": "images/sec", "cores": cores, "kind": "port",
             "sample": "%d timed train steps (1 warm-up) of the CPU oracle, UResNet ip%d fp32, batch %d, %dx%d, Adam" % (n, inplanes, B, size, size),
             "ms_per_step": 1e3 * el / n}
