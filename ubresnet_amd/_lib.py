@@ -37,7 +37,7 @@ class Tensor(C.Structure):
 
 
 class ChanAffine(C.Structure):
-    _fields_ = [("scale", C.c_void_p), ("shift", C.c_void_p), ("lo", C.c_void_p)]
+    _fields_ = [("sub", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p), ("lo", C.c_void_p)]
 
 
 class ConvDesc(C.Structure):
@@ -107,11 +107,11 @@ def _declare(lib):
     lib.ubr_stem_forward.argtypes = [i32, vp, i32, i32, i32, i32, vp, vp, i32, Tensor, vp, vp]
     lib.ubr_stem_wgrad.argtypes = [i32, vp, i32, i32, i32, i32, Tensor, i32, vp, i64, vp, vp, i32, vp]
     lib.ubr_bn_finalize.argtypes = [vp, f64, vp, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp]
-    lib.ubr_bn_eval_affine.argtypes = [vp, vp, vp, vp, f32, i32, vp, vp, vp]
+    lib.ubr_bn_eval_affine.argtypes = [vp, vp, vp, vp, f32, i32, vp, vp, vp, vp, vp]
     lib.ubr_bn_bwd_reduce.argtypes = [i32, i64, i32, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i32, vp, vp]
     lib.ubr_bn_bwd_finalize.argtypes = [vp, f64, vp, vp, i32, vp, vp, i32, vp, vp, vp]
     lib.ubr_bn_bwd_apply.argtypes = [i32, i64, i32, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i32, vp, vp, vp, i64, vp]
-    lib.ubr_block_tail_fwd.argtypes = [i32, i64, i32, vp, i64, vp, vp, vp, i64, vp, vp, vp, i64, vp]
+    lib.ubr_block_tail_fwd.argtypes = [i32, i64, i32, vp, i64, vp, vp, vp, vp, i64, vp, vp, vp, vp, i64, vp]
     lib.ubr_block_tail_bwd_reduce.argtypes = [i32, i64, i32, vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp,
                                               vp, i64, vp, vp, vp, vp, vp]
     lib.ubr_block_tail_bwd_apply.argtypes = [i32, i64, i32, vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp,

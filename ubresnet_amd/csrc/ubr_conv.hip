@@ -20,7 +20,7 @@ namespace {
 
 struct ConvK {
   const char* x; long x_sn, x_sy, x_sx;        // byte strides
-  const float *in_scale, *in_shift, *in_lo;
+  const float *in_sub, *in_scale, *in_shift, *in_lo;
   const char* w;
   char* y; long y_sn, y_sy, y_sx;
   const char* ad; long a_sn, a_sy, a_sx;
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK k) {
           ET<T>::unpack(v, f);
 #pragma unroll
           for (int e = 0; e < CPU; ++e)
-            f[e] = fmaxf(fmaf(f[e], k.in_scale[ch0 + e], k.in_shift[ch0 + e]), k.in_lo[ch0 + e]);
+            f[e] = fmaxf(fmaf(f[e] - k.in_sub[ch0 + e], k.in_scale[ch0 + e], k.in_shift[ch0 + e]), k.in_lo[ch0 + e]);
           v = ET<T>::pack(f);
         }
       }
@@ -350,7 +350,7 @@ extern "C" int ubr_conv(const ubr_conv_desc* d, void* stream) {
             "ubr_conv: input strides must keep 16-byte alignment");
   UBR_CHECK(d->x.sx >= d->Cin, "ubr_conv: x pixel stride %ld < Cin %d", (long)d->x.sx, d->Cin);
   const bool xf = d->xf.scale != nullptr;
-  UBR_CHECK(xf == (d->xf.shift != nullptr) && xf == (d->xf.lo != nullptr), "ubr_conv: xf needs scale, shift and lo together");
+  UBR_CHECK(xf == (d->xf.shift != nullptr) && xf == (d->xf.lo != nullptr) && xf == (d->xf.sub != nullptr), "ubr_conv: xf needs sub, scale, shift and lo together");
   if (d->epilogue == 0) {
     UBR_CHECK(d->Cout % 4 == 0, "ubr_conv: NHWC store needs Cout %% 4 == 0 (got %d)", d->Cout);
     UBR_CHECK((((uintptr_t)d->y.p) % (4 * esz)) == 0 && d->y.sx % 4 == 0 && d->y.sy % 4 == 0 && d->y.sn % 4 == 0,
@@ -400,7 +400,7 @@ extern "C" int ubr_conv(const ubr_conv_desc* d, void* stream) {
 
   ConvK k{};
   k.x = (const char*)d->x.p; k.x_sn = d->x.sn * esz; k.x_sy = d->x.sy * esz; k.x_sx = d->x.sx * esz;
-  k.in_scale = d->xf.scale; k.in_shift = d->xf.shift; k.in_lo = d->xf.lo;
+  k.in_sub = d->xf.sub; k.in_scale = d->xf.scale; k.in_shift = d->xf.shift; k.in_lo = d->xf.lo;
   k.w = (const char*)d->w;
   k.y = (char*)d->y.p; k.y_sn = d->y.sn * esz; k.y_sy = d->y.sy * esz; k.y_sx = d->y.sx * esz;
   k.ad = (const char*)d->addend.p; k.a_sn = d->addend.sn * esz; k.a_sy = d->addend.sy * esz; k.a_sx = d->addend.sx * esz;

@@ -68,22 +68,22 @@ __device__ __forceinline__ void flush_sums(const float (*acc)[CPU], int c, int C
 // BasicBlock tail forward
 // ------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void tail_fwd_kernel(long npix, int CU, const void* c2, long c2_ps, const float* s2, const float* t2,
-                                                       const void* sc, long sc_ps, const float* sb, const float* tb, void* out, long out_ps) {
+__global__ __launch_bounds__(256) void tail_fwd_kernel(long npix, int CU, const void* c2, long c2_ps, const float* m2p, const float* s2, const float* t2,
+                                                       const void* sc, long sc_ps, const float* mbp, const float* sb, const float* tb, void* out, long out_ps) {
   constexpr int CPU = ET<T>::CPU;
   UnitIdx<T> ix(CU);
-  float a2[CPU], b2[CPU], ab[CPU], bb[CPU];
-  ldconst<CPU>(s2, ix.c, a2); ldconst<CPU>(t2, ix.c, b2);
+  float a2[CPU], b2[CPU], m2[CPU], ab[CPU], bb[CPU], mb[CPU];
+  ldconst<CPU>(s2, ix.c, a2); ldconst<CPU>(t2, ix.c, b2); ldconst<CPU>(m2p, ix.c, m2);
   const bool byp = sb != nullptr;
-  if (byp) { ldconst<CPU>(sb, ix.c, ab); ldconst<CPU>(tb, ix.c, bb); }
+  if (byp) { ldconst<CPU>(sb, ix.c, ab); ldconst<CPU>(tb, ix.c, bb); ldconst<CPU>(mbp, ix.c, mb); }
   for (long p = ix.p; p < npix; p += ix.pstep) {
     float v[CPU], s[CPU], o[CPU];
     ldunit<T>(c2, p, c2_ps, ix.c, v);
     ldunit<T>(sc, p, sc_ps, ix.c, s);
 #pragma unroll
     for (int e = 0; e < CPU; ++e) {
-      const float r2 = fmaxf(fmaf(v[e], a2[e], b2[e]), 0.f);
-      const float sh = byp ? fmaf(s[e], ab[e], bb[e]) : s[e];
+      const float r2 = fmaxf(fmaf(v[e] - m2[e], a2[e], b2[e]), 0.f);
+      const float sh = byp ? fmaf(s[e] - mb[e], ab[e], bb[e]) : s[e];
       o[e] = fmaxf(r2 + sh, 0.f);
     }
     stunit<T>(out, p, out_ps, ix.c, o);
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(const TailB k) {
 #pragma unroll
     for (int e = 0; e < CPU; ++e) {
       const float gz = o[e] > 0.f ? g[e] : 0.f;
-      const float gy2 = fmaf(c2[e], s2[e], t2[e]) > 0.f ? gz : 0.f;
+      const float gy2 = fmaf(c2[e] - m2[e], s2[e], t2[e]) > 0.f ? gz : 0.f;
       const float xh2 = (c2[e] - m2[e]) * i2[e];
       if (APPLY) {
         r2[e] = s2[e] * (gy2 - k12[e] - xh2 * k22[e]);
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnB k) {
     ldunit<T>(k.c, p, k.c_ps, ix.c, c);
 #pragma unroll
     for (int e = 0; e < CPU; ++e) {
-      const float gy = (!k.relu || fmaf(c[e], sc[e], sh[e]) > 0.f) ? g[e] : 0.f;
+      const float gy = (!k.relu || fmaf(c[e] - mu[e], sc[e], sh[e]) > 0.f) ? g[e] : 0.f;
       const float xh = (c[e] - mu[e]) * is[e];
       if (APPLY) r[e] = sc[e] * (gy - k1[e] - xh * k2[e]);
       else { acc[0][e] += gy; acc[1][e] += gy * xh; }
@@ -239,7 +239,7 @@ __global__ void bn_finalize_kernel(const double* stats, double count, const floa
   const double is = 1.0 / sqrt(var + (double)eps);
   const float sc = (float)((double)gamma[c] * is);
   scale[c] = sc;
-  shift[c] = (float)((double)beta[c] - m * (double)gamma[c] * is);
+  shift[c] = beta[c];   // bn(x) = (x - mean)*scale + shift
   mean[c] = (float)m;
   invstd[c] = (float)is;
   if (rmean != nullptr) {
@@ -249,13 +249,14 @@ __global__ void bn_finalize_kernel(const double* stats, double count, const floa
   }
 }
 __global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, const float* rmean, const float* rvar,
-                                      float eps, int C, float* scale, float* shift) {
+                                      float eps, int C, float* scale, float* shift, float* mean, float* invstd) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const float is = 1.0f / sqrtf(rvar[c] + eps);
-  const float sc = gamma[c] * is;
-  scale[c] = sc;
-  shift[c] = beta[c] - rmean[c] * sc;
+  scale[c] = gamma[c] * is;
+  shift[c] = beta[c];
+  mean[c] = rmean[c];
+  invstd[c] = is;
 }
 __global__ void bn_bwd_finalize_kernel(const double* red, double count, int C, float* dgamma, float* dbeta, int accumulate,
                                        float* k1, float* k2) {
@@ -280,7 +281,7 @@ __global__ void cast_f64_kernel(const double* src, float* dst, int n, double sca
 struct PoolK {
   int N, H, W, OH, OW, C, CU, stride;
   const void* x; long x_ps;
-  const float *scale, *shift, *lo;
+  const float *sub, *scale, *shift, *lo;
   void* pooled; long p_ps;
   void* xcopy; long xc_ps;
   const void* gp; long gp_ps;
@@ -293,8 +294,8 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const PoolK k) {
   constexpr int CPU = ET<T>::CPU;
   UnitIdx<T> ix(k.CU);
   const bool xf = k.scale != nullptr;
-  float sc[CPU], sh[CPU], lo[CPU];
-  if (xf) { ldconst<CPU>(k.scale, ix.c, sc); ldconst<CPU>(k.shift, ix.c, sh); ldconst<CPU>(k.lo, ix.c, lo); }
+  float sc[CPU], sh[CPU], lo[CPU], sb[CPU];
+  if (xf) { ldconst<CPU>(k.scale, ix.c, sc); ldconst<CPU>(k.shift, ix.c, sh); ldconst<CPU>(k.lo, ix.c, lo); ldconst<CPU>(k.sub, ix.c, sb); }
   const long npix = (long)k.N * k.OH * k.OW;
   for (long p = ix.p; p < npix; p += ix.pstep) {
     const int ox = (int)(p % k.OW);
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const PoolK k) {
         ldunit<T>(k.x, ip, k.x_ps, ix.c, v);
         if (xf) {
 #pragma unroll
-          for (int e = 0; e < CPU; ++e) v[e] = fmaxf(fmaf(v[e], sc[e], sh[e]), lo[e]);
+          for (int e = 0; e < CPU; ++e) v[e] = fmaxf(fmaf(v[e] - sb[e], sc[e], sh[e]), lo[e]);
         }
 #pragma unroll
         for (int e = 0; e < CPU; ++e) m[e] = fmaxf(m[e], v[e]);
@@ -334,8 +335,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const PoolK k) {
   constexpr int CPU = ET<T>::CPU;
   UnitIdx<T> ix(k.CU);
   const bool xf = k.scale != nullptr;
-  float sc[CPU], sh[CPU], lo[CPU];
-  if (xf) { ldconst<CPU>(k.scale, ix.c, sc); ldconst<CPU>(k.shift, ix.c, sh); ldconst<CPU>(k.lo, ix.c, lo); }
+  float sc[CPU], sh[CPU], lo[CPU], sb[CPU];
+  if (xf) { ldconst<CPU>(k.scale, ix.c, sc); ldconst<CPU>(k.shift, ix.c, sh); ldconst<CPU>(k.lo, ix.c, lo); ldconst<CPU>(k.sub, ix.c, sb); }
   const long npix = (long)k.N * k.H * k.W;
   const int s = k.stride;
   for (long p = ix.p; p < npix; p += ix.pstep) {
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const PoolK k) {
             ldunit<T>(k.x, ((long)n * k.H + yy) * k.W + xx, k.x_ps, ix.c, v);
             if (xf) {
 #pragma unroll
-              for (int e = 0; e < CPU; ++e) v[e] = fmaxf(fmaf(v[e], sc[e], sh[e]), lo[e]);
+              for (int e = 0; e < CPU; ++e) v[e] = fmaxf(fmaf(v[e] - sb[e], sc[e], sh[e]), lo[e]);
             }
             const bool here = (yy == iy) && (xx == jx);
 #pragma unroll
@@ -408,17 +409,17 @@ static int check_nhwc(const char* who, int dtype, int64_t npix, int C, const voi
 }
 #define UBR_TRY(x) do { int rc__ = (x); if (rc__ != UBR_OK) return rc__; } while (0)
 
-extern "C" int ubr_block_tail_fwd(int dtype, int64_t npix, int C, const void* c2, int64_t c2_ps, const float* scale2,
-                                  const float* shift2, const void* sc, int64_t sc_ps, const float* scale_b,
+extern "C" int ubr_block_tail_fwd(int dtype, int64_t npix, int C, const void* c2, int64_t c2_ps, const float* mean2, const float* scale2,
+                                  const float* shift2, const void* sc, int64_t sc_ps, const float* mean_b, const float* scale_b,
                                   const float* shift_b, void* out, int64_t out_ps, void* stream) {
   UBR_TRY(check_nhwc("ubr_block_tail_fwd(c2)", dtype, npix, C, c2, c2_ps));
   UBR_TRY(check_nhwc("ubr_block_tail_fwd(sc)", dtype, npix, C, sc, sc_ps));
   UBR_TRY(check_nhwc("ubr_block_tail_fwd(out)", dtype, npix, C, out, out_ps));
-  UBR_CHECK(scale2 && shift2 && ((scale_b == nullptr) == (shift_b == nullptr)), "ubr_block_tail_fwd: bad affine pointers");
+  UBR_CHECK(mean2 && scale2 && shift2 && ((scale_b == nullptr) == (shift_b == nullptr)) && ((scale_b == nullptr) == (mean_b == nullptr)), "ubr_block_tail_fwd: bad affine pointers");
   const int CU = C / ubr_cpu(dtype);
   const int blocks = pick_blocks(npix, CU);
   UBR_DT_SWITCH(dtype, hipLaunchKernelGGL(tail_fwd_kernel<TT>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (long)npix, CU, c2, (long)c2_ps,
-                                          scale2, shift2, sc, (long)sc_ps, scale_b, shift_b, out, (long)out_ps));
+                                          mean2, scale2, shift2, sc, (long)sc_ps, mean_b, scale_b, shift_b, out, (long)out_ps));
   UBR_LAUNCH_CHECK("ubr_block_tail_fwd");
   return UBR_OK;
 }
@@ -538,9 +539,10 @@ extern "C" int ubr_bn_finalize(const double* stats, double count, const float* g
   return UBR_OK;
 }
 extern "C" int ubr_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
-                                  const float* running_var, float eps, int C, float* scale, float* shift, void* stream) {
-  UBR_CHECK(gamma && beta && running_mean && running_var && scale && shift && C > 0, "ubr_bn_eval_affine: bad arguments");
-  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(ubr_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, gamma, beta, running_mean, running_var, eps, C, scale, shift);
+                                  const float* running_var, float eps, int C, float* scale, float* shift,
+                                  float* mean, float* invstd, void* stream) {
+  UBR_CHECK(gamma && beta && running_mean && running_var && scale && shift && mean && invstd && C > 0, "ubr_bn_eval_affine: bad arguments");
+  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(ubr_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, gamma, beta, running_mean, running_var, eps, C, scale, shift, mean, invstd);
   UBR_LAUNCH_CHECK("ubr_bn_eval_affine");
   return UBR_OK;
 }
@@ -574,10 +576,10 @@ static int pool_common(bool bwd, int dtype, int N, int H, int W, int C, int stri
   const int64_t npix_in = (int64_t)N * H * W, npix_out = (int64_t)N * OH * OW;
   UBR_TRY(check_nhwc(who, dtype, npix_in, C, x, x_ps));
   const bool hx = xf.scale != nullptr;
-  UBR_CHECK(hx == (xf.shift != nullptr) && hx == (xf.lo != nullptr), "%s: xf needs scale, shift and lo together", who);
+  UBR_CHECK(hx == (xf.shift != nullptr) && hx == (xf.lo != nullptr) && hx == (xf.sub != nullptr), "%s: xf needs sub, scale, shift and lo together", who);
   PoolK k{};
   k.N = N; k.H = H; k.W = W; k.OH = OH; k.OW = OW; k.C = C; k.CU = C / ubr_cpu(dtype); k.stride = stride;
-  k.x = x; k.x_ps = x_ps; k.scale = xf.scale; k.shift = xf.shift; k.lo = xf.lo;
+  k.x = x; k.x_ps = x_ps; k.sub = xf.sub; k.scale = xf.scale; k.shift = xf.shift; k.lo = xf.lo;
   if (!bwd) {
     UBR_TRY(check_nhwc(who, dtype, npix_out, C, pooled, p_ps));
     if (xcopy) {

@@ -21,7 +21,7 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 
 struct WgK {
   const char* x; long x_sn, x_sy, x_sx;
-  const float *in_scale, *in_shift, *in_lo;
+  const float *in_sub, *in_scale, *in_shift, *in_lo;
   const char* g; long g_sn, g_sy, g_sx;
   float* slabs;
   int N, H, W, GH, GW, Cin, Cout_pad;
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgK k) {
             float f[CPU];
             ET<T>::unpack(v, f);
 #pragma unroll
-            for (int e = 0; e < CPU; ++e) f[e] = fmaxf(fmaf(f[e], k.in_scale[ch0 + e], k.in_shift[ch0 + e]), k.in_lo[ch0 + e]);
+            for (int e = 0; e < CPU; ++e) f[e] = fmaxf(fmaf(f[e] - k.in_sub[ch0 + e], k.in_scale[ch0 + e], k.in_shift[ch0 + e]), k.in_lo[ch0 + e]);
             v = ET<T>::pack(f);
           }
         }
@@ -304,12 +304,12 @@ extern "C" int ubr_wgrad(const ubr_wgrad_desc* d, void* stream) {
             "ubr_wgrad: strides must keep 16-byte alignment");
   UBR_CHECK(d->x.sx >= d->Cin && d->g.sx >= d->Cout, "ubr_wgrad: pixel stride smaller than channel count");
   const bool xf = d->xf.scale != nullptr;
-  UBR_CHECK(xf == (d->xf.shift != nullptr) && xf == (d->xf.lo != nullptr), "ubr_wgrad: xf needs scale, shift and lo together");
+  UBR_CHECK(xf == (d->xf.shift != nullptr) && xf == (d->xf.lo != nullptr) && xf == (d->xf.sub != nullptr), "ubr_wgrad: xf needs sub, scale, shift and lo together");
   int dymin = 127, dxmin = 127;
   for (int t = 0; t < d->ntaps; ++t) { dymin = d->dy[t] < dymin ? d->dy[t] : dymin; dxmin = d->dx[t] < dxmin ? d->dx[t] : dxmin; }
   WgK k{};
   k.x = (const char*)d->x.p; k.x_sn = d->x.sn * esz; k.x_sy = d->x.sy * esz; k.x_sx = d->x.sx * esz;
-  k.in_scale = d->xf.scale; k.in_shift = d->xf.shift; k.in_lo = d->xf.lo;
+  k.in_sub = d->xf.sub; k.in_scale = d->xf.scale; k.in_shift = d->xf.shift; k.in_lo = d->xf.lo;
   k.g = (const char*)d->g.p; k.g_sn = d->g.sn * esz; k.g_sy = d->g.sy * esz; k.g_sx = d->g.sx * esz;
   k.slabs = d->slabs;
   k.N = d->N; k.H = d->H; k.W = d->W; k.GH = d->GH; k.GW = d->GW; k.Cin = d->Cin; k.Cout_pad = d->Cout;

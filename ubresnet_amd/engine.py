@@ -85,7 +85,7 @@ class Engine:
         return t
 
     def relu_affine(self, site: BNSite) -> Affine:
-        return Affine(site.scale, site.shift, self.const(site.scale.device, 0.0, site.C))
+        return Affine(site.mean, site.scale, site.shift, self.const(site.scale.device, 0.0, site.C))
 
     def packed(self, param: torch.Tensor, dtype, orient: str) -> torch.Tensor:
         """cached packed image of a weight (repacked when the parameter changes)"""
@@ -147,7 +147,7 @@ class Engine:
                             m.running_var if track else None, m.num_batches_tracked if track else None,
                             mom, m.eps, site.scale, site.shift, site.mean, site.invstd)
         else:
-            ops.bn_eval_affine(m.weight, m.bias, m.running_mean, m.running_var, m.eps, site.scale, site.shift)
+            ops.bn_eval_affine(m.weight, m.bias, m.running_mean, m.running_var, m.eps, site.scale, site.shift, site.mean, site.invstd)
 
     # ------------------------------------------------------------------ BasicBlock
     def block_fwd(self, blk, x, out, training, dt):
@@ -171,9 +171,9 @@ class Engine:
             cb = torch.empty((N, OH, OW, Cout), dtype=dt, device=dev)
             ops.conv(x, self.packed(blk.bypass.weight, dt, "fwd"), cb, T1, Cout, S=S, stats=bnb.stats)
             self._finish_bn(bnb, cnt, training)
-            ops.block_tail_fwd(c2, bn2.scale, bn2.shift, cb, bnb.scale, bnb.shift, out)
+            ops.block_tail_fwd(c2, bn2.mean, bn2.scale, bn2.shift, cb, bnb.mean, bnb.scale, bnb.shift, out)
         else:
-            ops.block_tail_fwd(c2, bn2.scale, bn2.shift, x, None, None, out)
+            ops.block_tail_fwd(c2, bn2.mean, bn2.scale, bn2.shift, x, None, None, None, out)
         if not self._save:
             return None
         rec = Saved()

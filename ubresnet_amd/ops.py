@@ -87,18 +87,18 @@ def _ps(t: torch.Tensor) -> int:
 
 
 class Affine:
-    """per-channel (scale, shift, lo) folded into a consumer's operand load"""
-    __slots__ = ("scale", "shift", "lo")
+    """per-channel v -> max((v - sub)*scale + shift, lo) folded into a consumer's operand load"""
+    __slots__ = ("sub", "scale", "shift", "lo")
 
-    def __init__(self, scale, shift, lo):
-        self.scale, self.shift, self.lo = scale, shift, lo
+    def __init__(self, sub, scale, shift, lo):
+        self.sub, self.scale, self.shift, self.lo = sub, scale, shift, lo
 
     def c(self) -> L.ChanAffine:
-        return L.ChanAffine(self.scale.data_ptr(), self.shift.data_ptr(), self.lo.data_ptr())
+        return L.ChanAffine(self.sub.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(), self.lo.data_ptr())
 
 
 def _xf(a: Optional[Affine]) -> L.ChanAffine:
-    return a.c() if a is not None else L.ChanAffine(None, None, None)
+    return a.c() if a is not None else L.ChanAffine(None, None, None, None)
 
 
 # ------------------------------------------------------------------------------------------
@@ -280,9 +280,10 @@ def bn_finalize(stats, count, gamma, beta, rmean, rvar, nbt, momentum, eps, scal
                                     mean.data_ptr(), invstd.data_ptr(), L.stream_ptr()), "bn_finalize")
 
 
-def bn_eval_affine(gamma, beta, rmean, rvar, eps, scale, shift):
+def bn_eval_affine(gamma, beta, rmean, rvar, eps, scale, shift, mean, invstd):
     L.check(L.lib().ubr_bn_eval_affine(gamma.data_ptr(), beta.data_ptr(), rmean.data_ptr(), rvar.data_ptr(), float(eps),
-                                       gamma.numel(), scale.data_ptr(), shift.data_ptr(), L.stream_ptr()), "bn_eval_affine")
+                                       gamma.numel(), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                       L.stream_ptr()), "bn_eval_affine")
 
 
 def _npix(t):
@@ -314,10 +315,10 @@ def bn_bwd_apply(ga, ga2, c, scale, shift, mean, invstd, relu, k1, k2, gc):
 # BasicBlock tail
 # ------------------------------------------------------------------------------------------
 @_timed("block_tail_fwd")
-def block_tail_fwd(c2, scale2, shift2, sc, scale_b, shift_b, out):
-    L.check(L.lib().ubr_block_tail_fwd(L.dtype_id(c2.dtype), _npix(c2), c2.shape[3], c2.data_ptr(), _ps(c2), scale2.data_ptr(),
-                                       shift2.data_ptr(), sc.data_ptr(), _ps(sc), L.ptr(scale_b), L.ptr(shift_b),
-                                       out.data_ptr(), _ps(out), L.stream_ptr()), "block_tail_fwd")
+def block_tail_fwd(c2, mean2, scale2, shift2, sc, mean_b, scale_b, shift_b, out):
+    L.check(L.lib().ubr_block_tail_fwd(L.dtype_id(c2.dtype), _npix(c2), c2.shape[3], c2.data_ptr(), _ps(c2), mean2.data_ptr(),
+                                       scale2.data_ptr(), shift2.data_ptr(), sc.data_ptr(), _ps(sc), L.ptr(mean_b), L.ptr(scale_b),
+                                       L.ptr(shift_b), out.data_ptr(), _ps(out), L.stream_ptr()), "block_tail_fwd")
 
 
 @_timed("block_tail_bwd_reduce")
