@@ -73,6 +73,10 @@ CONV_CASES = [
     (1, 16, 24, 64, 16, 3, 1, 5, False, True, False, False, 0),
     (1, 4, 8, 512, 64, 3, 1, 1, False, False, True, False, 0),
     (1, 12, 20, 48, 32, 3, 1, 1, True, False, True, False, 0),   # ragged: not tile multiples, Cin=48
+    (1, 96, 128, 16, 16, 7, 1, 1, True, True, True, False, 0),    # head shapes of the 1x1x96x128 fixture
+    (1, 96, 128, 16, 16, 3, 1, 1, False, False, True, True, 0),
+    (1, 48, 64, 32, 32, 3, 1, 1, True, False, True, False, 0),
+    (2, 64, 96, 16, 16, 7, 1, 1, False, True, False, False, 0),
 ]
 
 
@@ -164,6 +168,11 @@ GRAD_CASES = [
     (1, 24, 24, 16, 16, 7, 1, False),
     (1, 12, 20, 48, 32, 3, 1, False),
     (1, 4, 8, 256, 128, 3, 1, False),
+    (1, 96, 128, 16, 16, 7, 1, True),
+    (1, 96, 128, 16, 16, 3, 1, False),
+    (1, 48, 64, 32, 32, 3, 1, True),
+    (2, 64, 96, 32, 16, 3, 1, False),
+    (1, 96, 128, 32, 16, 1, 1, False),
 ]
 
 
@@ -277,10 +286,9 @@ def test_bn_finalize(dt):
 
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("bypass", [False, True])
-@pytest.mark.parametrize("C", [16, 96])
-def test_block_tail(dt, bypass, C):
+@pytest.mark.parametrize("C,N,H,W", [(16, 2, 12, 20), (96, 2, 12, 20), (16, 1, 96, 128)])
+def test_block_tail(dt, bypass, C, N, H, W):
     """relu(relu(bn2(c2)) + shortcut) forward and the whole backward (both BatchNorms) vs autograd."""
-    N, H, W = 2, 12, 20
     c2 = rnd(dt, gen(N, C, H, W, seed=1))
     sc_in = rnd(dt, gen(N, C, H, W, seed=2))
     g2, b2 = _bn_vectors(C, 3)
@@ -335,8 +343,9 @@ def test_block_tail(dt, bypass, C):
 
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("relu", [True, False])
-def test_bn_backward(dt, relu):
-    N, C, H, W = 2, 32, 10, 12
+@pytest.mark.parametrize("shape", [(2, 32, 10, 12), (1, 16, 96, 128)])
+def test_bn_backward(dt, relu, shape):
+    N, C, H, W = shape
     c = rnd(dt, gen(N, C, H, W, seed=1))
     ga, ga2 = rnd(dt, gen(N, C, H, W, seed=2)), rnd(dt, gen(N, C, H, W, seed=3))
     gm, bt = _bn_vectors(C, 4)
