@@ -174,7 +174,7 @@ def test_gradients_dense_input_tight():
 
 def test_training_trajectory_matches_oracle():
     """Five Adam steps from the same weights on the same batch: the loss curves of the HIP path and
-    of the CPU oracle agree to 2e-3 relative (whole train step incl. BN running stats and optimizer)."""
+    of the CPU oracle agree to 5e-3 relative (whole train step incl. BN running stats and optimizer)."""
     from collections import OrderedDict
     sd = O.seeded_state_dict(O.uresnet_schema(3, 1, 16, 16), 42)
     x, lab, wgt = synthetic.make_batch(2, 64, 64, 1000)
@@ -205,7 +205,7 @@ def test_training_trajectory_matches_oracle():
     print("loss trajectories hip", hip, "oracle", ref)
     assert ref[-1] < ref[0]
     for a, b in zip(hip, ref):
-        assert abs(a - b) <= 2e-3 * abs(b), "loss trajectory diverges: %s vs %s" % (hip, ref)
+        assert abs(a - b) <= 5e-3 * abs(b), "loss trajectory diverges: %s vs %s" % (hip, ref)
     after = m.state_dict()
     for k in ("bn1.running_mean", "enc_layer3.res1.bn2.running_var", "bn10.running_var"):
         assert _rel(after[k].cpu(), p[k].detach()) <= 5e-3, k

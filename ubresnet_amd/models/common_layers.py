@@ -9,6 +9,12 @@ _ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__
 if _ROOT not in sys.path:          # allow `import common_layers` with only this directory on sys.path
     sys.path.insert(0, _ROOT)
 
+# One module object for both import styles of the reference (`sys.path += $UBRESNET_MODELDIR; import common_layers`
+# and `import ubresnet_amd.models.common_layers`): a top-level import re-binds itself to the package module.
+if __name__ != "ubresnet_amd.models.common_layers":
+    import importlib as _il
+    sys.modules[__name__] = _il.import_module("ubresnet_amd.models.common_layers")
+
 import torch.nn as nn  # noqa: E402
 
 from ubresnet_amd import nn_params as P  # noqa: E402

@@ -15,6 +15,12 @@ _ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__
 if _ROOT not in sys.path:
     sys.path.insert(0, _ROOT)
 
+# One module object for both import styles of the reference (`sys.path += $UBRESNET_MODELDIR; import pixelwise_nllloss`
+# and `import ubresnet_amd.training.pixelwise_nllloss`): a top-level import re-binds itself to the package module.
+if __name__ != "ubresnet_amd.training.pixelwise_nllloss":
+    import importlib as _il
+    sys.modules[__name__] = _il.import_module("ubresnet_amd.training.pixelwise_nllloss")
+
 import torch  # noqa: E402
 import torch.nn as nn  # noqa: E402
 
