@@ -123,7 +123,7 @@ typedef struct {
 /* returns the number of slabs the launch will use for this shape (>=1) and the workspace bytes */
 int ubr_wgrad_plan(const ubr_wgrad_desc* d, int32_t* nsplit, int64_t* workspace_bytes);
 int ubr_wgrad(const ubr_wgrad_desc* d, void* stream);
-int ubr_wgrad_reduce(const float* slabs, int nsplit, int ntaps, int Cout_pad, int Cin,
+int ubr_wgrad_reduce(float* slabs /* clobbered */, int nsplit, int ntaps, int Cout_pad, int Cin,
                      int Cout_valid, int Cin_valid, float* dst, int64_t sm, int64_t sk,
                      const int32_t* tapidx_host, int accumulate, void* stream);
 
@@ -138,6 +138,10 @@ int ubr_stem_wgrad(int dtype, const float* x_nchw, int N, int Cin, int H, int W,
                    float* partial /*workspace*/, int64_t partial_bytes, float* dweight, float* dbias,
                    int accumulate, void* stream);
 int64_t ubr_stem_wgrad_workspace(int N, int Cin, int H, int W, int Cout);
+/* Stem on the matrix cores: expand the NCHW fp32 image into NHWC with 16 channels per plane,
+ * channel kx (0..6) = the plane shifted by kx-3 columns (7..15 zero).  conv1 then is a 7-tap
+ * vertical convolution over 16*Cin channels run by ubr_conv / ubr_wgrad. */
+int ubr_stem_expand(int dtype, const float* x_nchw, int N, int Cin, int H, int W, void* out, int64_t out_ps, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * BatchNorm2d (eps, momentum from the module; e.g. models/common_layers.py:24)

@@ -150,3 +150,48 @@ def test_conv_transpose_layer(golden_dir):
     assert _rel(got, p["d.deconv.weight"].grad) <= 5e-4, "deconv weight gradient"
     got = grads["mod.res.res2.conv2.weight"][:8, :8]
     assert _rel(got, p["d.res.res2.conv2.weight"].grad) <= 5e-4
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [(2, 1, 40, 64, 16), (1, 3, 32, 32, 32)])
+def test_stem_on_matrix_cores(cfg, dt):
+    """conv1 7x7 (+bias, BN statistics) and its weight/bias gradients through the 16-channel column expansion."""
+    import torch.nn.functional as F
+    from ubresnet_amd import nn_params as P
+    N, Cin, H, W, Cout = cfg
+
+    class Stem(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv1 = P.Conv2d(Cin, Cout, kernel_size=7, stride=1, padding=3, bias=True)
+
+        def _grad_completion_order(self, prefix):
+            return [(prefix + "conv1.weight", self.conv1.weight), (prefix + "conv1.bias", self.conv1.bias)]
+
+    st = Stem().to(DEV)
+    eng = Engine(_Wrap(st), "custom")
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    x[x.abs() < 1.0] = 0.0
+    xq = x.to(dt).float()                       # the expansion stores the image in the compute type
+    w, b = st.conv1.weight.detach().cpu(), st.conv1.bias.detach().cpu()
+    wr, br = w.to(dt).float().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.conv2d(xq, wr, br, 1, 3)
+    c0 = torch.empty((N, H, W, Cout), dtype=dt, device=DEV)
+    stats = torch.zeros(2 * Cout, dtype=torch.float64, device=DEV)
+    x16 = eng.stem_fwd(st.conv1, x.to(DEV), c0, stats, dt)
+    torch.cuda.synchronize()
+    tol = 2e-5 if dt == torch.float32 else 1.2e-2
+    assert _rel(nchw(c0), ref.detach()) <= tol
+    assert _rel(stats[:Cout].cpu().float(), ref.detach().sum(dim=(0, 2, 3))) <= 10 * tol
+    go = torch.randn(N, Cout, H, W, generator=g).to(dt).float()
+    ref.backward(go)
+    flat = torch.zeros(eng.grad_numel, device=DEV)
+    views = {}
+    for name, p in eng.grad_order:
+        o = eng.grad_offsets[name]
+        views[id(p)] = flat[o:o + p.numel()].view(p.shape)
+    eng.stem_bwd(st.conv1, x16, go.permute(0, 2, 3, 1).contiguous().to(dt).to(DEV), lambda p: views[id(p)])
+    torch.cuda.synchronize()
+    assert _rel(views[id(st.conv1.weight)].cpu(), wr.grad) <= 4 * tol
+    assert _rel(views[id(st.conv1.bias)].cpu(), br.grad) <= 4 * tol

@@ -81,7 +81,7 @@ class WgradDesc(C.Structure):
 # every symbol include/ubresnet_hip.h declares (tests check that all of them are exported)
 SYMBOLS = [
     "ubr_conv", "ubr_pack_weights", "ubr_wgrad_plan", "ubr_wgrad", "ubr_wgrad_reduce",
-    "ubr_stem_forward", "ubr_stem_wgrad", "ubr_stem_wgrad_workspace",
+    "ubr_stem_forward", "ubr_stem_wgrad", "ubr_stem_wgrad_workspace", "ubr_stem_expand",
     "ubr_bn_finalize", "ubr_bn_eval_affine", "ubr_bn_bwd_reduce", "ubr_bn_bwd_finalize", "ubr_bn_bwd_apply",
     "ubr_block_tail_fwd", "ubr_block_tail_bwd_reduce", "ubr_block_tail_bwd_apply",
     "ubr_maxpool_fwd", "ubr_maxpool_bwd",
@@ -106,6 +106,7 @@ def _declare(lib):
     lib.ubr_wgrad_reduce.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, i64, i64, C.POINTER(C.c_int32), i32, vp]
     lib.ubr_stem_forward.argtypes = [i32, vp, i32, i32, i32, i32, vp, vp, i32, Tensor, vp, vp]
     lib.ubr_stem_wgrad.argtypes = [i32, vp, i32, i32, i32, i32, Tensor, i32, vp, i64, vp, vp, i32, vp]
+    lib.ubr_stem_expand.argtypes = [i32, vp, i32, i32, i32, i32, vp, i64, vp]
     lib.ubr_bn_finalize.argtypes = [vp, f64, vp, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp]
     lib.ubr_bn_eval_affine.argtypes = [vp, vp, vp, vp, f32, i32, vp, vp, vp, vp, vp]
     lib.ubr_bn_bwd_reduce.argtypes = [i32, i64, i32, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i32, vp, vp]

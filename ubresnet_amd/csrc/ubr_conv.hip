@@ -121,25 +121,45 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK k) {
   for (int blk = 0; blk < k.nblk; ++blk) {
     if (blk) __syncthreads();
     // ---- stage the input halo (transform + zero padding) ----
-    for (int i = tid; i < nitems; i += 256) {
-      const int hy = (int)__umulhi((unsigned)i, k.rw_magic);
-      const int rem = i - hy * (int)k.rw;
-      const int hx = rem >> k.lgUPB, c = rem & (k.UPB - 1);
-      const int iy = hy0 + hy, ix = hx0 + hx;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if ((unsigned)iy < (unsigned)k.H && (unsigned)ix < (unsigned)k.W) {
-        const int ch0 = (blk * k.UPB + c) * CPU;
-        v = ldg16(xn + (long)iy * k.x_sy + (long)ix * k.x_sx + (long)ch0 * ESZ);
-        if (has_xf) {
-          float f[CPU];
-          ET<T>::unpack(v, f);
+    // 256 % UPB == 0, so a thread's channel unit c is fixed: its BatchNorm constants are loaded once per
+    // cin block; global loads are issued in batches of SB before any LDS store.
+    {
+      constexpr int SB = 4;
+      const int c = tid & (k.UPB - 1);
+      const int ch0 = (blk * k.UPB + c) * CPU;
+      float xsub[CPU], xsc[CPU], xsh[CPU], xlo[CPU];
+      if (has_xf) {
 #pragma unroll
-          for (int e = 0; e < CPU; ++e)
-            f[e] = fmaxf(fmaf(f[e] - k.in_sub[ch0 + e], k.in_scale[ch0 + e], k.in_shift[ch0 + e]), k.in_lo[ch0 + e]);
-          v = ET<T>::pack(f);
+        for (int e = 0; e < CPU; ++e) { xsub[e] = k.in_sub[ch0 + e]; xsc[e] = k.in_scale[ch0 + e]; xsh[e] = k.in_shift[ch0 + e]; xlo[e] = k.in_lo[ch0 + e]; }
+      }
+      const char* xc = xn + (long)ch0 * ESZ;
+      for (int ib = tid; ib < nitems; ib += 256 * SB) {
+        uint4 v[SB];
+        int dst[SB];
+        bool ok[SB];
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+          const int i = ib + u * 256;
+          const int hy = (int)__umulhi((unsigned)i, k.rw_magic);
+          const int hx = (i - hy * (int)k.rw) >> k.lgUPB;
+          const int iy = hy0 + hy, ix = hx0 + hx;
+          dst[u] = (hy * k.HW + hx) * k.pixb + c * 16;
+          ok[u] = i < nitems && (unsigned)iy < (unsigned)k.H && (unsigned)ix < (unsigned)k.W;
+          v[u] = make_uint4(0u, 0u, 0u, 0u);
+          if (ok[u]) v[u] = ldg16(xc + (long)iy * k.x_sy + (long)ix * k.x_sx);
+        }
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+          if (has_xf && ok[u]) {
+            float f[CPU];
+            ET<T>::unpack(v[u], f);
+#pragma unroll
+            for (int e = 0; e < CPU; ++e) f[e] = fmaxf(fmaf(f[e] - xsub[e], xsc[e], xsh[e]), xlo[e]);
+            v[u] = ET<T>::pack(f);
+          }
+          if (ib + u * 256 < nitems) *reinterpret_cast<uint4*>(halo + dst[u]) = v[u];
         }
       }
-      *reinterpret_cast<uint4*>(halo + (hy * k.HW + hx) * k.pixb + c * 16) = v;
     }
     // ---- stage the weight slab: [unit][TN][16 B], zero beyond nunits ----
     for (int i = tid; i < 4 * k.steps * TN; i += 256) {

@@ -389,6 +389,81 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const PoolK k) {
   }
 }
 
+// stride-2 backward, one thread per pooled pixel: it owns the 2x2 input pixels (2oy..2oy+1, 2ox..2ox+1)
+// and scans the (up to) four windows that overlap them -- 36 unit loads for 4 outputs instead of 36 per output.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_s2_kernel(const PoolK k) {
+  constexpr int CPU = ET<T>::CPU;
+  UnitIdx<T> ix(k.CU);
+  const bool xf = k.scale != nullptr;
+  float sc[CPU], sh[CPU], lo[CPU], sb[CPU];
+  if (xf) { ldconst<CPU>(k.scale, ix.c, sc); ldconst<CPU>(k.shift, ix.c, sh); ldconst<CPU>(k.lo, ix.c, lo); ldconst<CPU>(k.sub, ix.c, sb); }
+  const long npix = (long)k.N * k.OH * k.OW;
+  for (long p = ix.p; p < npix; p += ix.pstep) {
+    const int ox = (int)(p % k.OW);
+    const long r = p / k.OW;
+    const int oy = (int)(r % k.OH);
+    const int n = (int)(r / k.OH);
+    float g[2][2][CPU];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        if (k.ge != nullptr) ldunit<T>(k.ge, ((long)n * k.H + 2 * oy + a) * k.W + 2 * ox + b, k.ge_ps, ix.c, g[a][b]);
+        else {
+#pragma unroll
+          for (int e = 0; e < CPU; ++e) g[a][b][e] = 0.f;
+        }
+      }
+#pragma unroll
+    for (int wy = 0; wy < 2; ++wy) {
+      if (oy + wy >= k.OH) continue;
+#pragma unroll
+      for (int wx = 0; wx < 2; ++wx) {
+        if (ox + wx >= k.OW) continue;
+        float best[CPU]; int bidx[CPU];
+#pragma unroll
+        for (int e = 0; e < CPU; ++e) { best[e] = -FLT_MAX; bidx[e] = -1; }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const int yy = 2 * (oy + wy) - 1 + ky;
+          if ((unsigned)yy >= (unsigned)k.H) continue;
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const int xx = 2 * (ox + wx) - 1 + kx;
+            if ((unsigned)xx >= (unsigned)k.W) continue;
+            float v[CPU];
+            ldunit<T>(k.x, ((long)n * k.H + yy) * k.W + xx, k.x_ps, ix.c, v);
+            if (xf) {
+#pragma unroll
+              for (int e = 0; e < CPU; ++e) v[e] = fmaxf(fmaf(v[e] - sb[e], sc[e], sh[e]), lo[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < CPU; ++e)
+              if (bidx[e] < 0 || v[e] > best[e]) { best[e] = v[e]; bidx[e] = ky * 3 + kx; }   // strict >: first maximum wins (ATen)
+          }
+        }
+        float gp[CPU];
+        ldunit<T>(k.gp, ((long)n * k.OH + oy + wy) * k.OW + ox + wx, k.gp_ps, ix.c, gp);
+        // tap (ky,kx) of window (wy,wx) is owned pixel (a,b) = (2wy-1+ky, 2wx-1+kx) when both are in {0,1}
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const int ky = a + 1 - 2 * wy, kx = b + 1 - 2 * wx;
+            if (ky < 0 || ky > 2 || kx < 0 || kx > 2) continue;
+#pragma unroll
+            for (int e = 0; e < CPU; ++e) if (bidx[e] == ky * 3 + kx) g[a][b][e] += gp[e];
+          }
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) stunit<T>(k.gx, ((long)n * k.H + 2 * oy + a) * k.W + 2 * ox + b, k.gx_ps, ix.c, g[a][b]);
+  }
+}
+
 template <typename K> struct Dispatch3 {};
 
 }  // namespace
@@ -594,8 +669,13 @@ static int pool_common(bool bwd, int dtype, int N, int H, int W, int C, int stri
     if (ge) UBR_TRY(check_nhwc(who, dtype, npix_in, C, ge, ge_ps));
     UBR_TRY(check_nhwc(who, dtype, npix_in, C, gx, gx_ps));
     k.gp = gp; k.gp_ps = gp_ps; k.ge = ge; k.ge_ps = ge_ps; k.gx = gx; k.gx_ps = gx_ps;
-    const int blocks = pick_blocks(npix_in, k.CU);
-    UBR_DT_SWITCH(dtype, hipLaunchKernelGGL(maxpool_bwd_kernel<TT>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, k));
+    if (stride == 2 && H % 2 == 0 && W % 2 == 0) {
+      const int blocks = pick_blocks(npix_out, k.CU);
+      UBR_DT_SWITCH(dtype, hipLaunchKernelGGL(maxpool_bwd_s2_kernel<TT>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, k));
+    } else {
+      const int blocks = pick_blocks(npix_in, k.CU);
+      UBR_DT_SWITCH(dtype, hipLaunchKernelGGL(maxpool_bwd_kernel<TT>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, k));
+    }
   }
   UBR_LAUNCH_CHECK(who);
   return UBR_OK;

@@ -187,6 +187,38 @@ __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* par
 }
 
 // ------------------------------------------------------------------------------------------
+// stem expansion: NCHW fp32 image -> NHWC T with 16 channels per image plane, channel kx (0..6)
+// holding the image shifted by kx-3 columns.  A 7x7 convolution over Cin planes then IS a
+// 7-tap (vertical) convolution over 16*Cin channels, which runs on the MFMA implicit-GEMM and
+// weight-gradient kernels (K = 7*16 per plane instead of 49; the zero channels cost no HBM).
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void stem_expand_kernel(const float* x, int N, int Cin, int H, int W, char* out, long out_ps) {
+  constexpr int CPU = ET<T>::CPU;
+  constexpr int ESZ = 16 / CPU;
+  const long hw = (long)H * W;
+  const long total = (long)N * Cin * hw;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int ci = (int)(i % Cin);
+    const long p = i / Cin;                 // pixel index over N*H*W
+    const long n = p / hw, r = p - n * hw;
+    const int xx = (int)(r % W);
+    const float* row = x + ((n * Cin + ci) * hw + (r - xx));
+    float f[16];
+#pragma unroll
+    for (int kx = 0; kx < 7; ++kx) {
+      const int sx = xx + kx - 3;
+      f[kx] = ((unsigned)sx < (unsigned)W) ? row[sx] : 0.f;
+    }
+#pragma unroll
+    for (int c = 7; c < 16; ++c) f[c] = 0.f;
+    char* dst = out + (p * out_ps + (long)ci * 16) * ESZ;
+#pragma unroll
+    for (int u = 0; u < 16 / CPU; ++u) stg16(dst + u * 16, ET<T>::pack(f + u * CPU));
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // LogSoftmax backward + re-layout
 // ------------------------------------------------------------------------------------------
 template <typename T>
@@ -288,6 +320,18 @@ extern "C" int ubr_stem_forward(int dtype, const float* x_nchw, int N, int Cin, 
                                           x_nchw, N, Cin, H, W, weight, bias, Cout, (char*)y.p, (long)y.sn * esz, (long)y.sy * esz,
                                           (long)y.sx * esz, stats, tiles_x, tiles_y));
   UBR_LAUNCH_CHECK("ubr_stem_forward");
+  return UBR_OK;
+}
+
+extern "C" int ubr_stem_expand(int dtype, const float* x_nchw, int N, int Cin, int H, int W, void* out, int64_t out_ps, void* stream) {
+  UBR_CHECK(ubr_dtype_ok(dtype), "ubr_stem_expand: bad dtype");
+  UBR_CHECK(x_nchw && out && N > 0 && H > 0 && W > 0 && Cin >= 1 && Cin <= 8, "ubr_stem_expand: bad arguments");
+  UBR_CHECK(ubr_aligned16(out) && out_ps >= 16 * Cin && (out_ps * ubr_esize(dtype)) % 16 == 0, "ubr_stem_expand: output pixel stride must be >= 16*Cin and 16-byte aligned");
+  long blocks = ((long)N * Cin * H * W + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  UBR_DT_SWITCH(dtype, hipLaunchKernelGGL(stem_expand_kernel<TT>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x_nchw, N, Cin, H, W,
+                                          (char*)out, (long)out_ps));
+  UBR_LAUNCH_CHECK("ubr_stem_expand");
   return UBR_OK;
 }
 

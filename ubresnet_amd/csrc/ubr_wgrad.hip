@@ -28,6 +28,7 @@ struct WgK {
   int ntaps, S, iy0, ix0, dymin, dxmin, HH, HW;
   int TH, tiles_x, tiles_y, ntiles;
   int pixbG, pixbX, x_off;
+  unsigned hw_magic;                             // ceil(2^32 / HW)
   int n_cot;
   int8_t dy[UBR_MAX_TAPS], dx[UBR_MAX_TAPS];
 };
@@ -72,6 +73,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgK k) {
 #pragma unroll
       for (int b = 0; b < NB; ++b) acc[t][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  constexpr int SB = 4;   // staging batch: loads in flight per thread
+  float xsub[CPU], xsc[CPU], xsh[CPU], xlo[CPU];
+  if (has_xf) {
+    const int ch0 = ci0 + (tid % UX) * CPU;
+#pragma unroll
+    for (int e = 0; e < CPU; ++e) { xsub[e] = k.in_sub[ch0 + e]; xsc[e] = k.in_scale[ch0 + e]; xsh[e] = k.in_shift[ch0 + e]; xlo[e] = k.in_lo[ch0 + e]; }
+  }
+
   for (int tile = blockIdx.x; tile < k.ntiles; tile += gridDim.x) {
     int tt = tile;
     const int tx = tt % k.tiles_x; tt /= k.tiles_x;
@@ -79,40 +88,61 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgK k) {
     const int n = tt / k.tiles_y;
     const int oy0 = ty * k.TH, ox0 = tx * 32;
     __syncthreads();   // previous tile fully consumed
-    // ---- stage gradient tile [TH*32 px][TCO] ----
+    // ---- stage gradient tile [TH*32 px][TCO] and input halo [HH*HW px][TCI] ----
+    // Each thread keeps ONE channel unit (256 % units-per-pixel == 0), so the BatchNorm constants of
+    // its channels sit in registers; loads are issued in batches of SB before any LDS store.
     {
       const char* gn = k.g + (long)n * k.g_sn;
-      const int nitems = k.TH * 32 * UG;
-      for (int i = tid; i < nitems; i += 256) {
-        const int c = i % UG, px = i / UG;
-        const int gy = oy0 + (px >> 5), gx = ox0 + (px & 31);
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (gy < k.GH && gx < k.GW) v = ldg16(gn + (long)gy * k.g_sy + (long)gx * k.g_sx + (long)(co0 + c * CPU) * ESZ);
-        *reinterpret_cast<uint4*>(gl + px * k.pixbG + c * 16) = v;
+      const int cg = tid % UG, pg0 = tid / UG;
+      constexpr int PGS = 256 / UG;
+      const int npx = k.TH * 32;
+      for (int pb = pg0; pb < npx; pb += PGS * SB) {
+        uint4 v[SB];
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+          const int px = pb + u * PGS;
+          const int gy = oy0 + (px >> 5), gx = ox0 + (px & 31);
+          v[u] = make_uint4(0u, 0u, 0u, 0u);
+          if (px < npx && gy < k.GH && gx < k.GW) v[u] = ldg16(gn + (long)gy * k.g_sy + (long)gx * k.g_sx + (long)(co0 + cg * CPU) * ESZ);
+        }
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+          const int px = pb + u * PGS;
+          if (px < npx) *reinterpret_cast<uint4*>(gl + px * k.pixbG + cg * 16) = v[u];
+        }
       }
     }
-    // ---- stage input halo [HH*HW px][TCI], transformed, zero padded ----
     {
       const char* xn = k.x + (long)n * k.x_sn;
       const int hy0 = oy0 * k.S + k.iy0 + k.dymin, hx0 = ox0 * k.S + k.ix0 + k.dxmin;
-      const int nitems = k.HH * k.HW * UX;
-      for (int i = tid; i < nitems; i += 256) {
-        const int c = i % UX, px = i / UX;
-        const int hy = px / k.HW, hx = px - hy * k.HW;
-        const int iy = hy0 + hy, ix = hx0 + hx;
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if ((unsigned)iy < (unsigned)k.H && (unsigned)ix < (unsigned)k.W) {
-          const int ch0 = ci0 + c * CPU;
-          v = ldg16(xn + (long)iy * k.x_sy + (long)ix * k.x_sx + (long)ch0 * ESZ);
-          if (has_xf) {
-            float f[CPU];
-            ET<T>::unpack(v, f);
+      const int cx = tid % UX, px0 = tid / UX;
+      constexpr int PXS_T = 256 / UX;
+      const int ch0 = ci0 + cx * CPU;
+      const int npx = k.HH * k.HW;
+      for (int pb = px0; pb < npx; pb += PXS_T * SB) {
+        uint4 v[SB];
+        bool ok[SB];
 #pragma unroll
-            for (int e = 0; e < CPU; ++e) f[e] = fmaxf(fmaf(f[e] - k.in_sub[ch0 + e], k.in_scale[ch0 + e], k.in_shift[ch0 + e]), k.in_lo[ch0 + e]);
-            v = ET<T>::pack(f);
-          }
+        for (int u = 0; u < SB; ++u) {
+          const int px = pb + u * PXS_T;
+          const int hy = (int)__umulhi((unsigned)px, k.hw_magic), hx = px - hy * k.HW;
+          const int iy = hy0 + hy, ix = hx0 + hx;
+          ok[u] = px < npx && (unsigned)iy < (unsigned)k.H && (unsigned)ix < (unsigned)k.W;
+          v[u] = make_uint4(0u, 0u, 0u, 0u);
+          if (ok[u]) v[u] = ldg16(xn + (long)iy * k.x_sy + (long)ix * k.x_sx + (long)ch0 * ESZ);
         }
-        *reinterpret_cast<uint4*>(xl + px * k.pixbX + c * 16) = v;
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+          const int px = pb + u * PXS_T;
+          if (has_xf && ok[u]) {
+            float f[CPU];
+            ET<T>::unpack(v[u], f);
+#pragma unroll
+            for (int e = 0; e < CPU; ++e) f[e] = fmaxf(fmaf(f[e] - xsub[e], xsc[e], xsh[e]), xlo[e]);
+            v[u] = ET<T>::pack(f);
+          }
+          if (px < npx) *reinterpret_cast<uint4*>(xl + px * k.pixbX + cx * 16) = v[u];
+        }
       }
     }
     __syncthreads();
@@ -262,9 +292,21 @@ int wdispatch(const WgK& k, const WPlan& p, hipStream_t st) {
 struct RedK {
   const float* slabs; float* dst;
   int nsplit, ntaps, Cout_pad, Cin, Cout_valid, Cin_valid, accumulate;
-  long sm, sk;
+  long sm, sk, slab_stride;
   int tapidx[UBR_MAX_TAPS];
 };
+constexpr int kRedGroup = 32;
+// stage 1: slabs [g*32, g*32+32) are summed (fixed order) into slab g*32, in place
+__global__ __launch_bounds__(256) void wgrad_reduce_stage1(float* slabs, long per, int nsplit) {
+  const int g = blockIdx.y;
+  const int s0 = g * kRedGroup, s1 = min(s0 + kRedGroup, nsplit);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per; i += (long)gridDim.x * 256) {
+    float s = 0.f;
+#pragma unroll 8
+    for (int sp = s0; sp < s1; ++sp) s += slabs[(long)sp * per + i];
+    slabs[(long)s0 * per + i] = s;
+  }
+}
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedK k) {
   const long per = (long)k.ntaps * k.Cout_pad * k.Cin;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per; i += (long)gridDim.x * 256) {
@@ -274,7 +316,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedK k) {
     const int t = (int)(r / k.Cout_pad);
     if (co >= k.Cout_valid || ci >= k.Cin_valid) continue;
     float s = 0.f;
-    for (int sp = 0; sp < k.nsplit; ++sp) s += k.slabs[(long)sp * per + i];
+#pragma unroll 8
+    for (int sp = 0; sp < k.nsplit; ++sp) s += k.slabs[(long)sp * k.slab_stride + i];
     float* d = k.dst + (long)co * k.sm + (long)ci * k.sk + k.tapidx[t];
     *d = k.accumulate ? (*d + s) : s;
   }
@@ -316,6 +359,7 @@ extern "C" int ubr_wgrad(const ubr_wgrad_desc* d, void* stream) {
   k.ntaps = d->ntaps; k.S = d->S; k.iy0 = d->iy0; k.ix0 = d->ix0; k.dymin = dymin; k.dxmin = dxmin; k.HH = p.HH; k.HW = p.HW;
   k.TH = p.TH; k.tiles_x = p.tiles_x; k.tiles_y = p.tiles_y; k.ntiles = p.ntiles;
   k.pixbG = p.pixbG; k.pixbX = p.pixbX; k.x_off = p.x_off;
+  k.hw_magic = (unsigned)((0x100000000ull + (unsigned)p.HW - 1) / (unsigned)p.HW);
   k.n_cot = d->Cout / (p.MA * 16);
   for (int t = 0; t < d->ntaps; ++t) { k.dy[t] = d->dy[t]; k.dx[t] = d->dx[t]; }
   hipStream_t st = (hipStream_t)stream;
@@ -326,20 +370,28 @@ extern "C" int ubr_wgrad(const ubr_wgrad_desc* d, void* stream) {
   }
 }
 
-extern "C" int ubr_wgrad_reduce(const float* slabs, int nsplit, int ntaps, int Cout_pad, int Cin,
+extern "C" int ubr_wgrad_reduce(float* slabs, int nsplit, int ntaps, int Cout_pad, int Cin,
                                 int Cout_valid, int Cin_valid, float* dst, int64_t sm, int64_t sk,
                                 const int32_t* tapidx_host, int accumulate, void* stream) {
   UBR_CHECK(slabs && dst && tapidx_host, "ubr_wgrad_reduce: null pointer");
-  UBR_CHECK(nsplit >= 1 && ntaps >= 1 && ntaps <= UBR_MAX_TAPS && Cout_pad > 0 && Cin > 0 &&
+  UBR_CHECK(nsplit >= 1 && nsplit <= kRedGroup * kRedGroup && ntaps >= 1 && ntaps <= UBR_MAX_TAPS && Cout_pad > 0 && Cin > 0 &&
             Cout_valid > 0 && Cout_valid <= Cout_pad && Cin_valid > 0 && Cin_valid <= Cin, "ubr_wgrad_reduce: bad extents");
-  RedK k{};
-  k.slabs = slabs; k.dst = dst; k.nsplit = nsplit; k.ntaps = ntaps; k.Cout_pad = Cout_pad; k.Cin = Cin;
-  k.Cout_valid = Cout_valid; k.Cin_valid = Cin_valid; k.accumulate = accumulate; k.sm = sm; k.sk = sk;
-  for (int t = 0; t < ntaps; ++t) k.tapidx[t] = tapidx_host[t];
   const long per = (long)ntaps * Cout_pad * Cin;
   int blocks = (int)((per + 255) / 256);
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, k);
+  hipStream_t st = (hipStream_t)stream;
+  RedK k{};
+  k.slabs = slabs; k.dst = dst; k.nsplit = nsplit; k.ntaps = ntaps; k.Cout_pad = Cout_pad; k.Cin = Cin;
+  k.Cout_valid = Cout_valid; k.Cin_valid = Cin_valid; k.accumulate = accumulate; k.sm = sm; k.sk = sk; k.slab_stride = per;
+  for (int t = 0; t < ntaps; ++t) k.tapidx[t] = tapidx_host[t];
+  if (nsplit > kRedGroup) {
+    // two-level tree keeps every thread's serial chain <= 32 loads (a single pass over 1024 slabs is latency-bound)
+    const int groups = ubr_cdiv(nsplit, kRedGroup);
+    hipLaunchKernelGGL(wgrad_reduce_stage1, dim3(blocks, groups), dim3(256), 0, st, slabs, per, nsplit);
+    UBR_LAUNCH_CHECK("ubr_wgrad_reduce(stage1)");
+    k.nsplit = groups; k.slab_stride = per * kRedGroup;
+  }
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, k);
   UBR_LAUNCH_CHECK("ubr_wgrad_reduce");
   return UBR_OK;
 }

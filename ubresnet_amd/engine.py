@@ -309,6 +309,44 @@ class Engine:
         ops.conv(g_up, wp, gx, ops.conv_taps(4, 1, 1), Cin, S=2)
         return gx, g_cat
 
+    # ------------------------------------------------------------------ stem
+    STEM_TAPS = [(ky - 3, 0, ky) for ky in range(7)]
+
+    def stem_fwd(self, conv1, x, c0, stats, dt):
+        """conv1 7x7 on the caller's NCHW image (models/ub_uresnet.py:41,94) on the matrix cores: the image is
+        expanded to 16 channels per plane (column shifts -3..3), then each plane is a 7-tap vertical conv."""
+        N, Cin, H, W = x.shape
+        Cout = conv1.out_channels
+        x16 = torch.empty((N, H, W, 16 * Cin), dtype=dt, device=x.device)
+        ops.stem_expand(x, x16)
+        w = conv1.weight
+        for ci in range(Cin):
+            key = (id(w), "stem%d" % ci, dt)
+            ver = (w._version, w.data_ptr())
+            hit = self._pack_cache.get(key)
+            if hit is None or hit[0] != ver:
+                # packed[ky][kx (7 of 16)][co] = w[co][ci][ky][kx]
+                pk = ops.pack_weights(w.detach(), dt, Cout, 7, Cin * 49, 1, 7, tapidx=[7 * ky for ky in range(7)],
+                                      Kpad=16, src_offset=ci * 49)
+                hit = (ver, pk)
+                self._pack_cache[key] = hit
+            last = ci == Cin - 1
+            ops.conv(x16[..., 16 * ci:16 * ci + 16], hit[1], c0, self.STEM_TAPS, Cout, bias=conv1.bias if ci == 0 else None,
+                     addend=c0 if ci > 0 else None, stats=stats if last else None)
+        return x16
+
+    def stem_bwd(self, conv1, x16, g_c0, G):
+        Cout = conv1.out_channels
+        Cin = x16.shape[3] // 16
+        dW = G(conv1.weight)
+        taps = [(ky - 3, 0, 7 * ky) for ky in range(7)]
+        for ci in range(Cin):
+            ops.wgrad(x16[..., 16 * ci:16 * ci + 16], g_c0, taps, dW, Cin * 49, 1, Cout, 7, self.wws, dst_offset=ci * 49)
+        red = torch.empty(Cout, dtype=torch.float64, device=g_c0.device)
+        ops.zero_(red)
+        ops.channel_sum(g_c0, red)
+        ops.cast_f64_to_f32(red, G(conv1.bias), Cout)
+
     # ------------------------------------------------------------------ UResNet
     def uresnet_forward(self, x: torch.Tensor, training: bool, dt: torch.dtype, save: bool):
         """training: BatchNorm uses batch statistics (and updates running stats); save: keep activations for backward"""
@@ -337,7 +375,7 @@ class Engine:
         # stem: conv1 -> (bn1 + relu folded into consumers) -> pool ; x0 goes into dec1's concat buffer
         bn1 = self.bn(m.bn1)
         c0 = E(N, H, W, ip)
-        ops.stem_forward(x, m.conv1.weight, m.conv1.bias, c0, bn1.stats)
+        x16 = self.stem_fwd(m.conv1, x, c0, bn1.stats, dt)
         self._finish_bn(bn1, N * H * W, training)
         cat1 = E(N, H, W, 2 * ip)
         p0 = E(N, H // 2, W // 2, ip)
@@ -379,7 +417,7 @@ class Engine:
                  bias=m.conv11.bias, logsoftmax=True)
         if not save:
             return out, None
-        sv.x, sv.c0, sv.cat1, sv.p0 = x, c0, cat1, p0
+        sv.x, sv.x16, sv.c0, sv.cat1, sv.p0 = x, x16, c0, cat1, p0
         sv.enc = (e1, e2, e3, e4, e5)
         sv.dec = (d1, d2, d3, d4, d5)
         sv.cats = (cat1, cat2, cat3, cat4, cat5)
@@ -457,7 +495,7 @@ class Engine:
         g_x0 = torch.empty(sv.c0.shape, dtype=dt, device=dev)
         ops.maxpool_bwd(sv.c0, self.relu_affine(bn1), g, gc1[..., ip:], g_x0, 2)
         g_c0 = self._bn_bwd(bn1, g_x0, None, sv.c0, True, G, N * H * W)
-        ops.stem_wgrad(sv.x, g_c0, G(m.conv1.weight), G(m.conv1.bias), self.wws)
+        self.stem_bwd(m.conv1, sv.x16, g_c0, G)
         stage_done(self.grad_order[-1][1])
         return flat, views
 

@@ -133,17 +133,18 @@ def transposed_phase_taps(k: int, dil: int, pad: int, s: int, ry: int, rx: int):
 # ------------------------------------------------------------------------------------------
 @_timed("pack_weights")
 def pack_weights(src: torch.Tensor, dtype: torch.dtype, M: int, K: int, sm: int, sk: int, ntaps: int,
-                 tapidx: Optional[Sequence[int]] = None) -> torch.Tensor:
-    """-> packed image [ntaps][Kpad/CPU][Mpad][CPU] (see ubr_pack_weights)"""
+                 tapidx: Optional[Sequence[int]] = None, Kpad: Optional[int] = None, src_offset: int = 0) -> torch.Tensor:
+    """-> packed image [ntaps][Kpad/CPU][Mpad][CPU] (see ubr_pack_weights); src_offset in elements"""
     L.require_cuda(src, "weights")
     assert src.dtype == torch.float32 and src.is_contiguous()
     cpu = L.chans_per_unit(dtype)
     Mpad = (M + 15) // 16 * 16
-    Kpad = (K + cpu - 1) // cpu * cpu
+    if Kpad is None:
+        Kpad = (K + cpu - 1) // cpu * cpu
     dst = torch.empty((ntaps, Kpad // cpu, Mpad, cpu), dtype=dtype, device=src.device)
     idx = (C.c_int32 * ntaps)(*(tapidx if tapidx is not None else range(ntaps)))
-    L.check(L.lib().ubr_pack_weights(L.dtype_id(dtype), src.data_ptr(), dst.data_ptr(), M, Mpad, K, Kpad, sm, sk, ntaps, idx,
-                                     L.stream_ptr()), "pack_weights")
+    L.check(L.lib().ubr_pack_weights(L.dtype_id(dtype), src.data_ptr() + 4 * src_offset, dst.data_ptr(), M, Mpad, K, Kpad, sm, sk,
+                                     ntaps, idx, L.stream_ptr()), "pack_weights")
     return dst
 
 
@@ -215,7 +216,8 @@ class WgradWorkspace:
 
 @_timed("wgrad")
 def wgrad(x: torch.Tensor, g: torch.Tensor, taps, dst: torch.Tensor, sm: int, sk: int, Cout_valid: int, Cin_valid: int,
-          ws: WgradWorkspace, S: int = 1, iy0: int = 0, ix0: int = 0, xf: Optional[Affine] = None, accumulate: bool = False):
+          ws: WgradWorkspace, S: int = 1, iy0: int = 0, ix0: int = 0, xf: Optional[Affine] = None, accumulate: bool = False,
+          dst_offset: int = 0):
     """dst[co*sm + ci*sk + tapidx] (+)= sum_pixels g[p][co] * xform(x)[p*S + tap][ci]
     taps: [(dy, dx, tapidx into the PyTorch weight layout)]"""
     d = L.WgradDesc()
@@ -242,7 +244,7 @@ def wgrad(x: torch.Tensor, g: torch.Tensor, taps, dst: torch.Tensor, sm: int, sk
     idx = (C.c_int32 * len(taps))(*[t[2] for t in taps])
     assert dst.dtype == torch.float32
     L.check(lib.ubr_wgrad_reduce(slabs.data_ptr(), nsplit.value, len(taps), d.Cout, Cin, Cout_valid, Cin_valid,
-                                 dst.data_ptr(), sm, sk, idx, 1 if accumulate else 0, st), "wgrad_reduce")
+                                 dst.data_ptr() + 4 * dst_offset, sm, sk, idx, 1 if accumulate else 0, st), "wgrad_reduce")
 
 
 # ------------------------------------------------------------------------------------------
@@ -257,6 +259,17 @@ def stem_forward(x_nchw, weight, bias, y, stats):
     assert weight.is_contiguous() and tuple(weight.shape) == (Cout, Cin, 7, 7)
     L.check(L.lib().ubr_stem_forward(L.dtype_id(y.dtype), x_nchw.data_ptr(), N, Cin, H, W, weight.data_ptr(), L.ptr(bias), Cout,
                                      _tv(y), L.ptr(stats), L.stream_ptr()), "stem_forward")
+
+
+@_timed("stem_expand")
+def stem_expand(x_nchw, out):
+    """NCHW fp32 image -> NHWC [N,H,W,16*Cin]: channel 16*ci+kx = plane ci shifted by kx-3 columns"""
+    L.require_cuda(x_nchw, "input image")
+    assert x_nchw.dtype == torch.float32 and x_nchw.is_contiguous()
+    N, Cin, H, W = x_nchw.shape
+    assert tuple(out.shape) == (N, H, W, 16 * Cin)
+    L.check(L.lib().ubr_stem_expand(L.dtype_id(out.dtype), x_nchw.data_ptr(), N, Cin, H, W, out.data_ptr(), _ps(out),
+                                    L.stream_ptr()), "stem_expand")
 
 
 @_timed("stem_wgrad")
