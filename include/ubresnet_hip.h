@@ -33,6 +33,11 @@ extern "C" {
 #define UBR_ELAUNCH (-2)  /* hip launch error */
 
 #define UBR_MAX_TAPS 64
+/* Every fp64 accumulator that many workgroups add into (`stats`, `red`, `acc`) is an array of
+ * UBR_STAT_SLOTS copies laid out [slot][n]; kernels add into slot blockIdx.x % UBR_STAT_SLOTS and
+ * the finalize / cast entry points sum the slots.  Callers allocate UBR_STAT_SLOTS * n doubles
+ * and zero them (ubr_zero) before the first accumulating launch. */
+#define UBR_STAT_SLOTS 32
 
 /* Strided NHWC view: element (n,y,x,c) lives at p + n*sn + y*sy + x*sx + c (strides in elements). */
 typedef struct {
@@ -231,7 +236,8 @@ int ubr_confusion(const float* logp_nchw, const int64_t* target, int N, int C, i
 
 /* per-channel sum over pixels of an NHWC tensor (conv bias gradients): out[c] (+)= sum_p g[p][c] */
 int ubr_channel_sum(int dtype, int64_t npix, int C, const void* g, int64_t g_ps, double* red, void* stream);
-int ubr_cast_f64_to_f32(const double* src, float* dst, int n, double scale, int accumulate, void* stream);
+/* dst[i] (+)= scale * sum_slots src[slot*stride + i] */
+int ubr_cast_f64_to_f32(const double* src, int stride, int slots, float* dst, int n, double scale, int accumulate, void* stream);
 int ubr_zero(void* p, int64_t bytes, void* stream);
 
 const char* ubr_last_error(void);

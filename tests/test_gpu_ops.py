@@ -50,6 +50,17 @@ def lo_zero(n):
     return torch.zeros(n, device=DEV)
 
 
+SLOTS = 32   # UBR_STAT_SLOTS: fp64 accumulators are [slot][n]
+
+
+def statbuf(n):
+    return torch.zeros(SLOTS * n, dtype=torch.float64, device=DEV)
+
+
+def slotsum(t, n):
+    return t.view(SLOTS, n).sum(0)
+
+
 CONV_CASES = [
     # N, H, W, Cin, Cout, k, stride, dil, xf, bias, stats, addend, tile_hint
     (2, 24, 40, 16, 16, 3, 1, 1, True, False, True, False, 0),
@@ -106,14 +117,14 @@ def test_conv_forward(case, dt):
     ybuf = torch.full((N, OH, OW, Cout + 32), 7.0, dtype=dt, device=DEV)
     yv = ybuf[..., 32:]
     wp = ops.pack_weights(w.to(DEV), dt, Cout, Cin, Cin * k * k, k * k, k * k)
-    st = torch.zeros(2 * Cout, dtype=torch.float64, device=DEV) if stats else None
+    st = statbuf(2 * Cout) if stats else None
     ops.conv(xbuf[..., 16:], wp, yv, ops.conv_taps(k, dil, pad), Cout, S=stride, xf=aff,
              bias=b.to(DEV) if bias else None, addend=nhwc(ad, dt) if addend else None, stats=st, tile_hint=hint)
     torch.cuda.synchronize()
     close(nchw(yv), ref, tol(dt), "conv out")
     assert (ybuf[..., :32].float() == 7.0).all(), "conv wrote outside its channel slice"
     if stats:
-        s = st.cpu()
+        s = slotsum(st, 2 * Cout).cpu()
         n = N * OH * OW
         rs, rss = ref.sum(dim=(0, 2, 3)).double(), (ref.double() ** 2).sum(dim=(0, 2, 3))
         assert (s[:Cout] - rs).abs().max().item() <= tol(dt) * n * max(ref.abs().max().item(), 1e-6)
@@ -231,12 +242,13 @@ def test_stem(cfg, dt):
     b = gen(Cout, seed=3)
     ref = F.conv2d(x, w, b, 1, 3)
     y = torch.empty((N, H, W, Cout), dtype=dt, device=DEV)
-    st = torch.zeros(2 * Cout, dtype=torch.float64, device=DEV)
+    st = statbuf(2 * Cout)
     ops.stem_forward(x.to(DEV), w.to(DEV), b.to(DEV), y, st)
     torch.cuda.synchronize()
     close(nchw(y), ref, tol(dt), "stem fwd")
-    close(st[:Cout].cpu().float(), ref.sum(dim=(0, 2, 3)), 1e-4, "stem stats sum")
-    close(st[Cout:].cpu().float(), (ref ** 2).sum(dim=(0, 2, 3)), 1e-4, "stem stats sumsq")
+    ss = slotsum(st, 2 * Cout).cpu().float()
+    close(ss[:Cout], ref.sum(dim=(0, 2, 3)), 1e-4, "stem stats sum")
+    close(ss[Cout:], (ref ** 2).sum(dim=(0, 2, 3)), 1e-4, "stem stats sumsq")
     g = rnd(dt, gen(N, Cout, H, W, seed=4))
     wr = w.clone().requires_grad_(True)
     br = b.clone().requires_grad_(True)
@@ -259,7 +271,9 @@ def _bn_vectors(C, seed):
 def test_bn_finalize(dt):
     C, n = 32, 5000
     v = gen(n, C, seed=1) * 2 + 3
-    st = torch.cat([v.double().sum(0), (v.double() ** 2).sum(0)]).to(DEV)
+    st = statbuf(2 * C)
+    st[:2 * C] = torch.cat([v.double().sum(0), (v.double() ** 2).sum(0)]).to(DEV) * 0.25
+    st[2 * C:4 * C] = st[:2 * C] * 3      # spread over two slots: the finalize sums all slots
     gamma, beta = _bn_vectors(C, 2)
     rm, rv = gen(C, seed=4).to(DEV), (gen(C, seed=5).abs() + 0.5).to(DEV)
     rm0, rv0 = rm.clone().cpu(), rv.clone().cpu()
@@ -315,16 +329,16 @@ def test_block_tail(dt, bypass, C, N, H, W):
     ops.block_tail_fwd(c2d, d(m2), d(s2), d(t2), scd, d(mb) if bypass else None, d(sb) if bypass else None, d(tb) if bypass else None, outd)
     torch.cuda.synchronize()
     close(nchw(outd), out.detach(), tol(dt), "tail fwd")
-    red = torch.zeros(4 * C, dtype=torch.float64, device=DEV)
+    red2, redb = statbuf(2 * C), statbuf(2 * C)
     go1d, go2d = nhwc(go1, dt), nhwc(go2, dt)
     ops.block_tail_bwd_reduce(go1d, go2d, outd, c2d, d(s2), d(t2), d(m2), d(i2), scd if bypass else None,
-                              d(mb) if bypass else None, d(ib) if bypass else None, red[:2 * C], red[2 * C:] if bypass else None)
+                              d(mb) if bypass else None, d(ib) if bypass else None, red2, redb if bypass else None)
     k = torch.empty(4 * C, device=DEV)
     dg2, db2, dgb, dbb = [torch.empty(C, device=DEV) for _ in range(4)]
     cnt = N * H * W
-    ops.bn_bwd_finalize(red[:2 * C], cnt, C, dg2, db2, False, k[:C], k[C:2 * C])
+    ops.bn_bwd_finalize(red2, cnt, C, dg2, db2, False, k[:C], k[C:2 * C])
     if bypass:
-        ops.bn_bwd_finalize(red[2 * C:], cnt, C, dgb, dbb, False, k[2 * C:3 * C], k[3 * C:])
+        ops.bn_bwd_finalize(redb, cnt, C, dgb, dbb, False, k[2 * C:3 * C], k[3 * C:])
     g_c2 = torch.empty((N, H, W, C), dtype=dt, device=DEV)
     g_sc = torch.empty((N, H, W, C), dtype=dt, device=DEV)
     ops.block_tail_bwd_apply(go1d, go2d, outd, c2d, d(s2), d(t2), d(m2), d(i2), k[:C], k[C:2 * C],
@@ -357,7 +371,7 @@ def test_bn_backward(dt, relu, shape):
     istd = 1 / torch.sqrt(c.var(dim=(0, 2, 3), unbiased=False) + 1e-5)
     sc, sh = gm * istd, bt
     d = lambda t: t.to(DEV)
-    red = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
+    red = statbuf(2 * C)
     cd, gad, ga2d = nhwc(c, dt), nhwc(ga, dt), nhwc(ga2, dt)
     ops.bn_bwd_reduce(gad, ga2d, cd, d(sc), d(sh), d(m), d(istd), relu, red)
     k = torch.empty(2 * C, device=DEV)

@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(HERE, "libubresnet_hip.so")
 
 F32, BF16, F16 = 0, 1, 2
 MAX_TAPS = 64
+STAT_SLOTS = 32      # UBR_STAT_SLOTS
 _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 _CPU = {F32: 4, BF16: 8, F16: 8}
 
@@ -124,7 +125,7 @@ def _declare(lib):
     lib.ubr_pixelwise_nll_bwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i64, vp, vp]
     lib.ubr_confusion.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
     lib.ubr_channel_sum.argtypes = [i32, i64, i32, vp, i64, vp, vp]
-    lib.ubr_cast_f64_to_f32.argtypes = [vp, vp, i32, f64, i32, vp]
+    lib.ubr_cast_f64_to_f32.argtypes = [vp, i32, i32, vp, i32, f64, i32, vp]
     lib.ubr_zero.argtypes = [vp, i64, vp]
     for name in SYMBOLS:
         fn = getattr(lib, name)

@@ -112,12 +112,20 @@ template <> __device__ __forceinline__ f32x4 mma_step<f16_t>(f32x4 acc, const ui
 __device__ __forceinline__ uint4 ldg16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
 __device__ __forceinline__ void stg16(void* p, const uint4& v) { *reinterpret_cast<uint4*>(p) = v; }
 
+// fp64 accumulators that many workgroups add into are striped over UBR_STAT_SLOTS copies
+// (slot = blockIdx.x % UBR_STAT_SLOTS) and summed by the finalize kernels: thousands of same-address
+// atomics serialise at the memory side (a 16-channel layer's statistics were 60 % of its conv time).
+#define UBR_STAT_SLOTS 32
+
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float wave_quadrow_sum16(float v) {
-  // sum over the 16 lanes that share lane>>4 (xor butterflies stay inside the 16-lane row)
-  v += __shfl_xor(v, 1, 64);
-  v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 4, 64);
-  v += __shfl_xor(v, 8, 64);
+  // sum over the 16 lanes that share lane>>4, on the DPP path (no LDS traffic): every lane ends with the total
+  v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);   // row_half_mirror
+  v += dpp_mov<0x140>(v);   // row_mirror
   return v;
 }
 __device__ __forceinline__ float wave_sum64(float v) {

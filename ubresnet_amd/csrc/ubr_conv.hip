@@ -269,8 +269,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK k) {
         double a = 0.0, b = 0.0;
 #pragma unroll
         for (int w = 0; w < 4; ++w) { a += (double)red[(w * TN + tid) * 2]; b += (double)red[(w * TN + tid) * 2 + 1]; }
-        atomicAdd(&k.stats[ch], a);
-        atomicAdd(&k.stats[k.Cout + ch], b);
+        double* st = k.stats + (size_t)(blockIdx.x % UBR_STAT_SLOTS) * 2 * k.Cout;
+        atomicAdd(&st[ch], a);
+        atomicAdd(&st[k.Cout + ch], b);
       }
     }
   }

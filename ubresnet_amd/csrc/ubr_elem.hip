@@ -51,6 +51,7 @@ template <int CPU> __device__ __forceinline__ void ldconst(const float* a, int c
 // flush per-thread channel partials: LDS fp64 atomics, then one global fp64 atomic per channel
 template <int CPU, int NQ>
 __device__ __forceinline__ void flush_sums(const float (*acc)[CPU], int c, int C, double* lds, double* const* outs) {
+  // outs[qn] already point into this block's slot (callers add blockIdx.x % UBR_STAT_SLOTS)
   for (int i = threadIdx.x; i < NQ * C; i += 256) lds[i] = 0.0;
   __syncthreads();
 #pragma unroll
@@ -156,7 +157,8 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(const TailB k) {
     }
   }
   if (!APPLY) {
-    double* outs[4] = {k.red2, k.red2 + k.C, byp ? k.redb : nullptr, byp ? k.redb + k.C : nullptr};
+    const size_t so = (size_t)(blockIdx.x % UBR_STAT_SLOTS) * 2 * k.C;
+    double* outs[4] = {k.red2 + so, k.red2 + so + k.C, byp ? k.redb + so : nullptr, byp ? k.redb + so + k.C : nullptr};
     flush_sums<CPU, 4>(acc, ix.c, k.C, reinterpret_cast<double*>(smem), outs);
   }
 }
@@ -201,7 +203,8 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnB k) {
     if (APPLY) stunit<T>(k.gc, p, k.gc_ps, ix.c, r);
   }
   if (!APPLY) {
-    double* outs[2] = {k.red, k.red + k.C};
+    const size_t so = (size_t)(blockIdx.x % UBR_STAT_SLOTS) * 2 * k.C;
+    double* outs[2] = {k.red + so, k.red + so + k.C};
     flush_sums<CPU, 2>(acc, ix.c, k.C, reinterpret_cast<double*>(smem), outs);
   }
 }
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(long npix, int C, int 
 #pragma unroll
     for (int e = 0; e < CPU; ++e) acc[0][e] += v[e];
   }
-  double* outs[1] = {red};
+  double* outs[1] = {red + (size_t)(blockIdx.x % UBR_STAT_SLOTS) * C};
   flush_sums<CPU, 1>(acc, ix.c, C, reinterpret_cast<double*>(smem), outs);
 }
 
@@ -233,8 +236,10 @@ __global__ void bn_finalize_kernel(const double* stats, double count, const floa
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c == 0 && nbt != nullptr) *nbt += 1;
   if (c >= C) return;
-  const double m = stats[c] / count;
-  double var = stats[C + c] / count - m * m;
+  double s1 = 0.0, s2 = 0.0;
+  for (int sl = 0; sl < UBR_STAT_SLOTS; ++sl) { s1 += stats[(size_t)sl * 2 * C + c]; s2 += stats[(size_t)sl * 2 * C + C + c]; }
+  const double m = s1 / count;
+  double var = s2 / count - m * m;
   if (var < 0.0) var = 0.0;
   const double is = 1.0 / sqrt(var + (double)eps);
   const float sc = (float)((double)gamma[c] * is);
@@ -262,16 +267,19 @@ __global__ void bn_bwd_finalize_kernel(const double* red, double count, int C, f
                                        float* k1, float* k2) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const double sg = red[c], sgx = red[C + c];
+  double sg = 0.0, sgx = 0.0;
+  for (int sl = 0; sl < UBR_STAT_SLOTS; ++sl) { sg += red[(size_t)sl * 2 * C + c]; sgx += red[(size_t)sl * 2 * C + C + c]; }
   if (dgamma != nullptr) dgamma[c] = accumulate ? dgamma[c] + (float)sgx : (float)sgx;
   if (dbeta != nullptr) dbeta[c] = accumulate ? dbeta[c] + (float)sg : (float)sg;
   k1[c] = (float)(sg / count);
   k2[c] = (float)(sgx / count);
 }
-__global__ void cast_f64_kernel(const double* src, float* dst, int n, double scale, int accumulate) {
+__global__ void cast_f64_kernel(const double* src, float* dst, int n, int stride, int slots, double scale, int accumulate) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const float v = (float)(src[i] * scale);
+  double a = 0.0;
+  for (int sl = 0; sl < slots; ++sl) a += src[(size_t)sl * stride + i];
+  const float v = (float)(a * scale);
   dst[i] = accumulate ? dst[i] + v : v;
 }
 
@@ -629,9 +637,9 @@ extern "C" int ubr_bn_bwd_finalize(const double* red, double count, const float*
   UBR_LAUNCH_CHECK("ubr_bn_bwd_finalize");
   return UBR_OK;
 }
-extern "C" int ubr_cast_f64_to_f32(const double* src, float* dst, int n, double scale, int accumulate, void* stream) {
-  UBR_CHECK(src && dst && n > 0, "ubr_cast_f64_to_f32: bad arguments");
-  hipLaunchKernelGGL(cast_f64_kernel, dim3(ubr_cdiv(n, 128)), dim3(128), 0, (hipStream_t)stream, src, dst, n, scale, accumulate);
+extern "C" int ubr_cast_f64_to_f32(const double* src, int stride, int slots, float* dst, int n, double scale, int accumulate, void* stream) {
+  UBR_CHECK(src && dst && n > 0 && slots >= 1 && stride >= n, "ubr_cast_f64_to_f32: bad arguments");
+  hipLaunchKernelGGL(cast_f64_kernel, dim3(ubr_cdiv(n, 128)), dim3(128), 0, (hipStream_t)stream, src, dst, n, stride, slots, scale, accumulate);
   UBR_LAUNCH_CHECK("ubr_cast_f64_to_f32");
   return UBR_OK;
 }

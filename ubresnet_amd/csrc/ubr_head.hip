@@ -91,8 +91,9 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* x, int N, in
     if (tid < Cout) {
       double a = 0.0, b = 0.0;
       for (int w = 0; w < 4; ++w) { a += (double)red[(w * Cout + tid) * 2]; b += (double)red[(w * Cout + tid) * 2 + 1]; }
-      atomicAdd(&stats[tid], a);
-      atomicAdd(&stats[Cout + tid], b);
+      double* st = stats + (size_t)(blockIdx.x % UBR_STAT_SLOTS) * 2 * Cout;
+      atomicAdd(&st[tid], a);
+      atomicAdd(&st[Cout + tid], b);
     }
   }
 }
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(256) void nll_fwd_kernel(const float* pred, const l
   s = wave_sum64d(s);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(acc, part[0] + part[1] + part[2] + part[3]);
+  if (threadIdx.x == 0) atomicAdd(acc + (blockIdx.x % UBR_STAT_SLOTS), part[0] + part[1] + part[2] + part[3]);
 }
 
 __global__ __launch_bounds__(256) void nll_bwd_kernel(const float* gloss, const long long* target, const float* pw, const float* cw,

@@ -123,12 +123,13 @@ class Engine:
             s.invstd = sv.fws[off:off + s.C]; off += s.C
         sv.sites = [(s, s.scale, s.shift, s.mean, s.invstd) for s in self.bn_sites]
         if training:
-            nd = sum(2 * s.C for s in self.bn_sites)
+            S = L.STAT_SLOTS
+            nd = sum(2 * s.C for s in self.bn_sites) * S
             sv.dws = torch.empty(nd, dtype=torch.float64, device=device)
             ops.zero_(sv.dws)
             off = 0
             for s in self.bn_sites:
-                s.stats = sv.dws[off:off + 2 * s.C]; off += 2 * s.C
+                s.stats = sv.dws[off:off + 2 * s.C * S]; off += 2 * s.C * S
         else:
             for s in self.bn_sites:
                 s.stats = None
@@ -182,8 +183,7 @@ class Engine:
 
     def _bn_bwd(self, site: BNSite, ga, ga2, c, relu, G, cnt):
         """backward through a = relu(bn(c)) (or bn only): returns g_c; writes dgamma/dbeta"""
-        red = torch.empty(2 * site.C, dtype=torch.float64, device=c.device)
-        ops.zero_(red)
+        red = ops.stat_buffer(2 * site.C, c.device)
         ops.bn_bwd_reduce(ga, ga2, c, site.scale, site.shift, site.mean, site.invstd, relu, red)
         k = torch.empty(2 * site.C, dtype=torch.float32, device=c.device)
         k1, k2 = k[:site.C], k[site.C:]
@@ -221,11 +221,10 @@ class Engine:
         bn1, bn2 = self.bn(blk.bn1), self.bn(blk.bn2)
         byp = cb is not None
         bnb = self.bn(blk.bnpass) if byp else None
-        nred = 4 if byp else 2
-        red = torch.empty(nred * Cout, dtype=torch.float64, device=dev)
-        ops.zero_(red)
-        red2 = red[:2 * Cout]
-        redb = red[2 * Cout:] if byp else None
+        S = L.STAT_SLOTS
+        red = ops.stat_buffer((4 if byp else 2) * Cout, dev)
+        red2 = red[:2 * Cout * S]
+        redb = red[2 * Cout * S:] if byp else None
         ops.block_tail_bwd_reduce(go, go2, out, c2, bn2.scale, bn2.shift, bn2.mean, bn2.invstd,
                                   cb, bnb.mean if byp else None, bnb.invstd if byp else None, red2, redb)
         k = torch.empty(4 * Cout, dtype=torch.float32, device=dev)
@@ -342,8 +341,7 @@ class Engine:
         taps = [(ky - 3, 0, 7 * ky) for ky in range(7)]
         for ci in range(Cin):
             ops.wgrad(x16[..., 16 * ci:16 * ci + 16], g_c0, taps, dW, Cin * 49, 1, Cout, 7, self.wws, dst_offset=ci * 49)
-        red = torch.empty(Cout, dtype=torch.float64, device=g_c0.device)
-        ops.zero_(red)
+        red = ops.stat_buffer(Cout, g_c0.device)
         ops.channel_sum(g_c0, red)
         ops.cast_f64_to_f32(red, G(conv1.bias), Cout)
 
@@ -458,10 +456,10 @@ class Engine:
         bn10 = self.bn(m.bn10)
         nk = m.conv10.out_channels
         ops.wgrad(sv.c10, g_l, T7, G(m.conv11.weight), nk * 49, 49, ncls, nk, self.wws, xf=self.relu_affine(bn10))
-        red = torch.empty(16 + nk, dtype=torch.float64, device=dev)
-        ops.zero_(red)
-        ops.channel_sum(g_l, red[:16])
-        ops.cast_f64_to_f32(red[:16], G(m.conv11.bias), ncls)
+        S = L.STAT_SLOTS
+        red = ops.stat_buffer(16 + nk, dev)
+        ops.channel_sum(g_l, red[:16 * S])
+        ops.cast_f64_to_f32(red[:16 * S], G(m.conv11.bias), ncls, stride=16)
         g_a10 = torch.empty((N, H, W, nk), dtype=dt, device=dev)
         # data gradient of conv11: K = the 16 (zero-padded) logit channels
         wp = self._packed_dgrad_padded(m.conv11.weight, dt)
@@ -470,8 +468,8 @@ class Engine:
         g_c10 = self._bn_bwd(bn10, g_a10, None, sv.c10, True, G, N * H * W)
         del g_a10
         ops.wgrad(sv.d1o, g_c10, T7, G(m.conv10.weight), ip * 49, 49, nk, ip, self.wws)
-        ops.channel_sum(g_c10, red[16:])
-        ops.cast_f64_to_f32(red[16:], G(m.conv10.bias), nk)
+        ops.channel_sum(g_c10, red[16 * S:])
+        ops.cast_f64_to_f32(red[16 * S:], G(m.conv10.bias), nk)
         g = torch.empty(sv.d1o.shape, dtype=dt, device=dev)
         self._conv_dgrad(m.conv10, g_c10, g, 1, k=7)
         del g_c10

@@ -192,7 +192,7 @@ def conv(x: torch.Tensor, wp: torch.Tensor, y: torch.Tensor, taps, Cout: int, S:
     d.bias = L.ptr(bias)
     d.stats = L.ptr(stats)
     if stats is not None:
-        assert stats.dtype == torch.float64 and stats.numel() >= 2 * Cout
+        assert stats.dtype == torch.float64 and stats.numel() >= 2 * Cout * L.STAT_SLOTS
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() >= Cout
     if xf is not None:
@@ -407,9 +407,17 @@ def channel_sum(g, red):
                                     L.stream_ptr()), "channel_sum")
 
 
-def cast_f64_to_f32(src, dst, n, scale=1.0, accumulate=False):
-    L.check(L.lib().ubr_cast_f64_to_f32(src.data_ptr(), dst.data_ptr(), n, float(scale), 1 if accumulate else 0, L.stream_ptr()),
-            "cast_f64_to_f32")
+def stat_buffer(n: int, device) -> torch.Tensor:
+    """zeroed fp64 accumulator [UBR_STAT_SLOTS][n] (see include/ubresnet_hip.h)"""
+    t = torch.empty(L.STAT_SLOTS * n, dtype=torch.float64, device=device)
+    zero_(t)
+    return t
+
+
+def cast_f64_to_f32(src, dst, n, scale=1.0, accumulate=False, stride=None, slots=L.STAT_SLOTS):
+    """dst[:n] (+)= scale * sum over slots of src[slot*stride : slot*stride+n]"""
+    L.check(L.lib().ubr_cast_f64_to_f32(src.data_ptr(), n if stride is None else stride, slots, dst.data_ptr(), n, float(scale),
+                                        1 if accumulate else 0, L.stream_ptr()), "cast_f64_to_f32")
 
 
 def zero_(t: torch.Tensor):

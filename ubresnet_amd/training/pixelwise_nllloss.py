@@ -46,11 +46,10 @@ class _PixelNLLFn(torch.autograd.Function):
             raise RuntimeError("PixelWiseNLLLoss: shape mismatch predict %s target %s pixelweights %s"
                                % (tuple(predict.shape), tuple(target.shape), tuple(pixelweights.shape)))
         predict, target, pixelweights = predict.contiguous(), target.contiguous(), pixelweights.contiguous()
-        acc = torch.empty(1, dtype=torch.float64, device=predict.device)
-        ops.zero_(acc)
+        acc = ops.stat_buffer(1, predict.device)
         ops.pixelwise_nll_fwd(predict, target, pixelweights, classw, ignore_index, acc)
         loss = torch.empty((), dtype=torch.float32, device=predict.device)
-        ops.cast_f64_to_f32(acc, loss, 1, 1.0 / float(target.numel()))
+        ops.cast_f64_to_f32(acc, loss, 1, 1.0 / float(target.numel()), stride=1)
         ctx.save_for_backward(target, pixelweights)
         ctx.classw, ctx.ignore_index, ctx.shape = classw, ignore_index, tuple(predict.shape)
         return loss
