@@ -123,13 +123,13 @@ class Engine:
             s.invstd = sv.fws[off:off + s.C]; off += s.C
         sv.sites = [(s, s.scale, s.shift, s.mean, s.invstd) for s in self.bn_sites]
         if training:
-            S = L.STAT_SLOTS
-            nd = sum(2 * s.C for s in self.bn_sites) * S
+            NS = L.STAT_SLOTS
+            nd = sum(2 * s.C for s in self.bn_sites) * NS
             sv.dws = torch.empty(nd, dtype=torch.float64, device=device)
             ops.zero_(sv.dws)
             off = 0
             for s in self.bn_sites:
-                s.stats = sv.dws[off:off + 2 * s.C * S]; off += 2 * s.C * S
+                s.stats = sv.dws[off:off + 2 * s.C * NS]; off += 2 * s.C * NS
         else:
             for s in self.bn_sites:
                 s.stats = None
@@ -221,10 +221,10 @@ class Engine:
         bn1, bn2 = self.bn(blk.bn1), self.bn(blk.bn2)
         byp = cb is not None
         bnb = self.bn(blk.bnpass) if byp else None
-        S = L.STAT_SLOTS
+        NS = L.STAT_SLOTS
         red = ops.stat_buffer((4 if byp else 2) * Cout, dev)
-        red2 = red[:2 * Cout * S]
-        redb = red[2 * Cout * S:] if byp else None
+        red2 = red[:2 * Cout * NS]
+        redb = red[2 * Cout * NS:] if byp else None
         ops.block_tail_bwd_reduce(go, go2, out, c2, bn2.scale, bn2.shift, bn2.mean, bn2.invstd,
                                   cb, bnb.mean if byp else None, bnb.invstd if byp else None, red2, redb)
         k = torch.empty(4 * Cout, dtype=torch.float32, device=dev)
@@ -456,10 +456,10 @@ class Engine:
         bn10 = self.bn(m.bn10)
         nk = m.conv10.out_channels
         ops.wgrad(sv.c10, g_l, T7, G(m.conv11.weight), nk * 49, 49, ncls, nk, self.wws, xf=self.relu_affine(bn10))
-        S = L.STAT_SLOTS
+        NS = L.STAT_SLOTS
         red = ops.stat_buffer(16 + nk, dev)
-        ops.channel_sum(g_l, red[:16 * S])
-        ops.cast_f64_to_f32(red[:16 * S], G(m.conv11.bias), ncls, stride=16)
+        ops.channel_sum(g_l, red[:16 * NS])
+        ops.cast_f64_to_f32(red[:16 * NS], G(m.conv11.bias), ncls, stride=16)
         g_a10 = torch.empty((N, H, W, nk), dtype=dt, device=dev)
         # data gradient of conv11: K = the 16 (zero-padded) logit channels
         wp = self._packed_dgrad_padded(m.conv11.weight, dt)
@@ -468,8 +468,8 @@ class Engine:
         g_c10 = self._bn_bwd(bn10, g_a10, None, sv.c10, True, G, N * H * W)
         del g_a10
         ops.wgrad(sv.d1o, g_c10, T7, G(m.conv10.weight), ip * 49, 49, nk, ip, self.wws)
-        ops.channel_sum(g_c10, red[16 * S:])
-        ops.cast_f64_to_f32(red[16 * S:], G(m.conv10.bias), nk)
+        ops.channel_sum(g_c10, red[16 * NS:])
+        ops.cast_f64_to_f32(red[16 * NS:], G(m.conv10.bias), nk)
         g = torch.empty(sv.d1o.shape, dtype=dt, device=dev)
         self._conv_dgrad(m.conv10, g_c10, g, 1, k=7)
         del g_c10
