@@ -132,9 +132,11 @@ def test_conv_forward(case, dt):
 
 
 @pytest.mark.parametrize("dt", DTS + [torch.float16])
-def test_deconv_forward_and_grads(dt):
+@pytest.mark.parametrize("chans", [(32, 16), (128, 64)])
+def test_deconv_forward_and_grads(dt, chans):
     """ConvTranspose2d(k4,s2,p1) as 4 phases into a concat slice; its data and weight gradients."""
-    N, H, W, Cin, Cd = 2, 8, 12, 32, 16
+    N, H, W = 2, 8, 12
+    Cin, Cd = chans
     x = rnd(dt, gen(N, Cin, H, W, seed=1))
     w = gen(Cin, Cd, 4, 4, seed=2, scale=0.1)
     xr = x.clone().requires_grad_(True)
@@ -184,6 +186,11 @@ GRAD_CASES = [
     (1, 48, 64, 32, 32, 3, 1, True),
     (2, 64, 96, 32, 16, 3, 1, False),
     (1, 96, 128, 32, 16, 1, 1, False),
+    (2, 16, 16, 64, 64, 3, 1, True),       # wide layers: N-split weight-gradient tiles (64 x 64 channels)
+    (1, 16, 16, 64, 128, 3, 2, False),
+    (1, 16, 16, 128, 64, 1, 1, False),
+    (1, 8, 8, 128, 64, 1, 2, False),
+    (2, 12, 20, 64, 64, 3, 1, False),
 ]
 
 

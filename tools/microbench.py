@@ -32,7 +32,7 @@ if what.startswith("conv"):
     x, y = mk(N, HW, HW, Cin), torch.empty((N, HW, HW, Cout), dtype=dt, device=dev)
     w = torch.randn(Cout, Cin, k, k, device=dev) * 0.05
     wp = ops.pack_weights(w, dt, Cout, Cin, Cin * k * k, k * k, k * k)
-    st = torch.zeros(2 * Cout, dtype=torch.float64, device=dev)
+    st = torch.zeros(32 * 2 * Cout, dtype=torch.float64, device=dev)
     xf = aff(Cin) if "noxf" not in sys.argv else None
     stats = st if "nostats" not in sys.argv else None
     fn = lambda: ops.conv(x, wp, y, ops.conv_taps(k, 1, k // 2), Cout, xf=xf, stats=stats)

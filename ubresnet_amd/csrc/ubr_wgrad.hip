@@ -46,8 +46,14 @@ __device__ __forceinline__ uint4 sc_frag32(const char* p0, int pstride) {
                     *reinterpret_cast<const uint32_t*>(p0 + 2 * pstride), *reinterpret_cast<const uint32_t*>(p0 + 3 * pstride));
 }
 
-template <typename T, int MA, int NB, int TPG>
+// NSPLIT = false: the 4 waves split the pixel rows (K) and their partial sums meet in LDS (thin layers).
+// NSPLIT = true : the 4 waves split the cin fragments (N), every wave walks all rows: a 64 x 64-channel tile
+//                 with 9 taps costs the same 144 accumulator registers per wave as a K-split 32 x 32 tile but
+//                 re-stages G and X half as often per flop and needs no cross-wave reduction (C >= 64 layers).
+template <typename T, int MA, int NB, int TPG, bool NSPLIT>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgK k) {
+  constexpr int NBW = NSPLIT ? NB / 4 : NB;     // cin fragments owned by one wave
+  static_assert(!NSPLIT || NB % 4 == 0, "N-split needs a multiple of 4 cin fragments");
   constexpr int CPU = ET<T>::CPU;
   constexpr int ESZ = 16 / CPU;
   constexpr int TCO = MA * 16, TCI = NB * 16;
@@ -65,13 +71,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgK k) {
   const int t0 = blockIdx.z * TPG;
   const bool has_xf = k.in_scale != nullptr;
 
-  f32x4 acc[TPG][MA][NB];
+  f32x4 acc[TPG][MA][NBW];
 #pragma unroll
   for (int t = 0; t < TPG; ++t)
 #pragma unroll
     for (int a = 0; a < MA; ++a)
 #pragma unroll
-      for (int b = 0; b < NB; ++b) acc[t][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int b = 0; b < NBW; ++b) acc[t][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nb0 = NSPLIT ? wave * NBW : 0;
 
   constexpr int SB = 4;   // staging batch: loads in flight per thread
   float xsub[CPU], xsc[CPU], xsh[CPU], xlo[CPU];
@@ -146,8 +153,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgK k) {
       }
     }
     __syncthreads();
-    // ---- MFMA: each wave takes rows wave, wave+4, ... ----
-    for (int r = wave; r < k.TH; r += 4) {
+    // ---- MFMA: K-split: wave takes rows wave, wave+4, ...; N-split: every wave takes every row ----
+    for (int r = NSPLIT ? 0 : wave; r < k.TH; r += NSPLIT ? 1 : 4) {
 #pragma unroll
       for (int ks = 0; ks < KSR; ++ks) {
         uint4 A[MA];
@@ -165,13 +172,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgK k) {
           if (t0 + t < k.ntaps) {
             const int ddy = k.dy[t0 + t] - k.dymin, ddx = k.dx[t0 + t] - k.dxmin;
 #pragma unroll
-            for (int b = 0; b < NB; ++b) {
+            for (int b = 0; b < NBW; ++b) {
               uint4 B;
               if constexpr (CPU == 8) {
-                const char* p = xl + ((r * k.S + ddy) * k.HW + (8 * q + (l16 >> 2)) * k.S + ddx) * k.pixbX + (l16 & 3) * 8 + b * 32;
+                const char* p = xl + ((r * k.S + ddy) * k.HW + (8 * q + (l16 >> 2)) * k.S + ddx) * k.pixbX + (l16 & 3) * 8 + (nb0 + b) * 32;
                 B = tr_frag16(p, 4 * k.S * k.pixbX);
               } else {
-                const char* p = xl + ((r * k.S + ddy) * k.HW + (ks * 16 + 4 * q) * k.S + ddx) * k.pixbX + l16 * 4 + b * 64;
+                const char* p = xl + ((r * k.S + ddy) * k.HW + (ks * 16 + 4 * q) * k.S + ddx) * k.pixbX + l16 * 4 + (nb0 + b) * 64;
                 B = sc_frag32(p, k.S * k.pixbX);
               }
 #pragma unroll
@@ -183,39 +190,57 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgK k) {
     }
   }
 
-  // ---- cross-wave sum in fixed order (wave 0,1,2,3) through LDS, then one slab write ----
-  float* red = reinterpret_cast<float*>(smem);
-  for (int w = 0; w < 4; ++w) {
-    __syncthreads();
-    if (wave == w) {
+  float* slab = k.slabs + (long)blockIdx.x * k.ntaps * k.Cout_pad * k.Cin;
+  if constexpr (NSPLIT) {
+    // every wave owns its cin fragments outright: write the slab straight from the accumulators
 #pragma unroll
-      for (int t = 0; t < TPG; ++t)
+    for (int t = 0; t < TPG; ++t) {
+      if (t0 + t < k.ntaps) {
 #pragma unroll
         for (int a = 0; a < MA; ++a)
 #pragma unroll
-          for (int b = 0; b < NB; ++b)
+          for (int b = 0; b < NBW; ++b)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              float* p = red + (((t * MA + a) * NB + b) * 4 + r) * 64 + lane;
-              *p = (w == 0) ? acc[t][a][b][r] : (*p + acc[t][a][b][r]);
+              const int co = co0 + a * 16 + 4 * q + r, ci = ci0 + (nb0 + b) * 16 + l16;
+              slab[((long)(t0 + t) * k.Cout_pad + co) * k.Cin + ci] = acc[t][a][b][r];
             }
+      }
     }
-  }
-  __syncthreads();
-  float* slab = k.slabs + (long)blockIdx.x * k.ntaps * k.Cout_pad * k.Cin;
-  for (int s = wave; s < TPG * MA * NB; s += 4) {
-    const int b = s % NB, a = (s / NB) % MA, t = s / (NB * MA);
-    if (t0 + t < k.ntaps) {
+  } else {
+    // ---- cross-wave sum in fixed order (wave 0,1,2,3) through LDS, then one slab write ----
+    float* red = reinterpret_cast<float*>(smem);
+    for (int w = 0; w < 4; ++w) {
+      __syncthreads();
+      if (wave == w) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int co = co0 + a * 16 + 4 * q + r, ci = ci0 + b * 16 + l16;
-        slab[((long)(t0 + t) * k.Cout_pad + co) * k.Cin + ci] = red[(s * 4 + r) * 64 + lane];
+        for (int t = 0; t < TPG; ++t)
+#pragma unroll
+          for (int a = 0; a < MA; ++a)
+#pragma unroll
+            for (int b = 0; b < NBW; ++b)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                float* p = red + (((t * MA + a) * NB + b) * 4 + r) * 64 + lane;
+                *p = (w == 0) ? acc[t][a][b][r] : (*p + acc[t][a][b][r]);
+              }
+      }
+    }
+    __syncthreads();
+    for (int s = wave; s < TPG * MA * NB; s += 4) {
+      const int b = s % NB, a = (s / NB) % MA, t = s / (NB * MA);
+      if (t0 + t < k.ntaps) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = co0 + a * 16 + 4 * q + r, ci = ci0 + b * 16 + l16;
+          slab[((long)(t0 + t) * k.Cout_pad + co) * k.Cin + ci] = red[(s * 4 + r) * 64 + lane];
+        }
       }
     }
   }
 }
 
-struct WPlan { int MA, NB, TPG, TH, HH, HW, pixbG, pixbX, x_off, tiles_x, tiles_y, ntiles, nsplit, gy, gz; size_t lds; };
+struct WPlan { int MA, NB, TPG, TH, HH, HW, pixbG, pixbX, x_off, tiles_x, tiles_y, ntiles, nsplit, gy, gz, nsplit_mode; size_t lds; };
 
 static int wgrad_plan(const ubr_wgrad_desc* d, WPlan* p) {
   UBR_CHECK(d != nullptr, "ubr_wgrad: null descriptor");
@@ -233,8 +258,13 @@ static int wgrad_plan(const ubr_wgrad_desc* d, WPlan* p) {
   int TPG = d->ntaps <= 1 ? 1 : d->ntaps <= 4 ? 4 : d->ntaps <= 9 ? 9 : 25;
   int MA = (d->Cout % 32 == 0) ? 2 : 1, NB = (d->Cin % 32 == 0) ? 2 : 1;
   if (TPG == 25) { MA = 1; NB = 1; }
-  p->MA = MA; p->NB = NB; p->TPG = TPG;
+  p->nsplit_mode = 0;
   p->TH = d->S == 1 ? 8 : 4;   // rows beyond GH are zero-filled, so small grids stay correct
+  if (TPG <= 9 && d->Cout % 64 == 0 && d->Cin % 64 == 0) {   // wide layers: 64 x 64 channel tile, waves split cin
+    MA = 4; NB = 4; p->nsplit_mode = 1;
+    p->TH = d->S == 1 ? 4 : 2;
+  }
+  p->MA = MA; p->NB = NB; p->TPG = TPG;
   p->HH = (p->TH - 1) * d->S + 1 + (dymax - dymin);
   p->HW = 31 * d->S + 1 + (dxmax - dxmin);
   p->pixbG = MA * 16 * esz + 16;
@@ -243,7 +273,7 @@ static int wgrad_plan(const ubr_wgrad_desc* d, WPlan* p) {
   gbytes = (gbytes + 15) & ~(size_t)15;
   p->x_off = (int)gbytes;
   size_t stage = gbytes + (size_t)p->HH * p->HW * p->pixbX;
-  size_t redb = (size_t)TPG * MA * NB * 4 * 64 * sizeof(float);
+  size_t redb = p->nsplit_mode ? 0 : (size_t)TPG * MA * NB * 4 * 64 * sizeof(float);
   p->lds = stage > redb ? stage : redb;
   UBR_CHECK(p->lds <= 160 * 1024, "ubr_wgrad: LDS need %zu exceeds 160 KiB", p->lds);
   p->tiles_x = ubr_cdiv(d->GW, 32); p->tiles_y = ubr_cdiv(d->GH, p->TH);
@@ -261,9 +291,9 @@ static int wgrad_plan(const ubr_wgrad_desc* d, WPlan* p) {
   return UBR_OK;
 }
 
-template <typename T, int MA, int NB, int TPG>
+template <typename T, int MA, int NB, int TPG, bool NSPLIT>
 int wlaunch(const WgK& k, const WPlan& p, hipStream_t st) {
-  auto fn = wgrad_kernel<T, MA, NB, TPG>;
+  auto fn = wgrad_kernel<T, MA, NB, TPG, NSPLIT>;
   if (p.lds > 64 * 1024) {
     static thread_local size_t maxset = 0;
     if (p.lds > maxset) {
@@ -279,7 +309,10 @@ int wlaunch(const WgK& k, const WPlan& p, hipStream_t st) {
 
 template <typename T>
 int wdispatch(const WgK& k, const WPlan& p, hipStream_t st) {
-#define UBR_WCASE(ma, nb, tpg) if (p.MA == ma && p.NB == nb && p.TPG == tpg) return wlaunch<T, ma, nb, tpg>(k, p, st);
+#define UBR_WCASE(ma, nb, tpg) if (!p.nsplit_mode && p.MA == ma && p.NB == nb && p.TPG == tpg) return wlaunch<T, ma, nb, tpg, false>(k, p, st);
+#define UBR_NCASE(tpg) if (p.nsplit_mode && p.MA == 4 && p.NB == 4 && p.TPG == tpg) return wlaunch<T, 4, 4, tpg, true>(k, p, st);
+  UBR_NCASE(1) UBR_NCASE(4) UBR_NCASE(9)
+#undef UBR_NCASE
   UBR_WCASE(1, 1, 1) UBR_WCASE(1, 2, 1) UBR_WCASE(2, 1, 1) UBR_WCASE(2, 2, 1)
   UBR_WCASE(1, 1, 4) UBR_WCASE(1, 2, 4) UBR_WCASE(2, 1, 4) UBR_WCASE(2, 2, 4)
   UBR_WCASE(1, 1, 9) UBR_WCASE(1, 2, 9) UBR_WCASE(2, 1, 9) UBR_WCASE(2, 2, 9)
