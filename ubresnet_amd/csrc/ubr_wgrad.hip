@@ -280,7 +280,9 @@ static int wgrad_plan(const ubr_wgrad_desc* d, WPlan* p) {
   p->ntiles = p->tiles_x * p->tiles_y * d->N;
   p->gy = (d->Cout / (MA * 16)) * (d->Cin / (NB * 16));
   p->gz = ubr_cdiv(d->ntaps, TPG);
-  int target = 1024 / (p->gy * p->gz);
+  // workgroups in flight: thin layers want many (tiny slabs, latency hiding by occupancy); for wide layers
+  // every extra split adds a full |dW| slab to write and re-read, so stay near one or two per CU
+  int target = (p->nsplit_mode ? 384 : 1024) / (p->gy * p->gz);
   if (target < 1) target = 1;
   // bound slab memory: at most 64 MiB of partials per launch
   const size_t slab_bytes = (size_t)d->ntaps * d->Cout * d->Cin * sizeof(float);
