@@ -151,8 +151,11 @@ class Engine:
             ops.bn_eval_affine(m.weight, m.bias, m.running_mean, m.running_var, m.eps, site.scale, site.shift, site.mean, site.invstd)
 
     # ------------------------------------------------------------------ BasicBlock
-    def block_fwd(self, blk, x, out, training, dt):
-        """BasicBlock.forward (models/common_layers.py:39-58); x, out: NHWC views."""
+    def block_fwd(self, blk, x, out, training, dt, xf_in=None):
+        """BasicBlock.forward (models/common_layers.py:39-58); x, out: NHWC views.
+        xf_in: per-channel affine of a virtual input (only for blocks with a bypass conv)."""
+        if xf_in is not None and blk.bypass is None:
+            raise RuntimeError("identity-shortcut block cannot take a virtual (affine) input")
         N, H, W, Cin = x.shape
         S = blk.stride
         OH, OW = out.shape[1], out.shape[2]
@@ -161,7 +164,7 @@ class Engine:
         bn1, bn2 = self.bn(blk.bn1), self.bn(blk.bn2)
         cnt = N * OH * OW
         c1 = torch.empty((N, OH, OW, Cout), dtype=dt, device=dev)
-        ops.conv(x, self.packed(blk.conv1.weight, dt, "fwd"), c1, T3, Cout, S=S, stats=bn1.stats)
+        ops.conv(x, self.packed(blk.conv1.weight, dt, "fwd"), c1, T3, Cout, S=S, xf=xf_in, stats=bn1.stats)
         self._finish_bn(bn1, cnt, training)
         c2 = torch.empty((N, OH, OW, Cout), dtype=dt, device=dev)
         ops.conv(c1, self.packed(blk.conv2.weight, dt, "fwd"), c2, T3, Cout, xf=self.relu_affine(bn1), stats=bn2.stats)
@@ -170,7 +173,7 @@ class Engine:
         if blk.bypass is not None:
             bnb = self.bn(blk.bnpass)
             cb = torch.empty((N, OH, OW, Cout), dtype=dt, device=dev)
-            ops.conv(x, self.packed(blk.bypass.weight, dt, "fwd"), cb, T1, Cout, S=S, stats=bnb.stats)
+            ops.conv(x, self.packed(blk.bypass.weight, dt, "fwd"), cb, T1, Cout, S=S, xf=xf_in, stats=bnb.stats)
             self._finish_bn(bnb, cnt, training)
             ops.block_tail_fwd(c2, bn2.mean, bn2.scale, bn2.shift, cb, bnb.mean, bnb.scale, bnb.shift, out)
         else:
@@ -178,7 +181,7 @@ class Engine:
         if not self._save:
             return None
         rec = Saved()
-        rec.blk, rec.x, rec.c1, rec.c2, rec.cb, rec.out = blk, x, c1, c2, cb, out
+        rec.blk, rec.x, rec.c1, rec.c2, rec.cb, rec.out, rec.xf_in = blk, x, c1, c2, cb, out, xf_in
         return rec
 
     def _bn_bwd(self, site: BNSite, ga, ga2, c, relu, G, cnt):
@@ -245,9 +248,9 @@ class Engine:
         g_c1 = self._bn_bwd(bn1, g_a1, None, c1, True, G, cnt)
         del g_a1
         Cin = x.shape[3]
-        ops.wgrad(x, g_c1, T3, G(blk.conv1.weight), Cin * kk, kk, Cout, Cin, self.wws, S=S)
+        ops.wgrad(x, g_c1, T3, G(blk.conv1.weight), Cin * kk, kk, Cout, Cin, self.wws, S=S, xf=rec.xf_in)
         if byp:
-            ops.wgrad(x, g_sc, T1, G(blk.bypass.weight), Cin, 1, Cout, Cin, self.wws, S=S)
+            ops.wgrad(x, g_sc, T1, G(blk.bypass.weight), Cin, 1, Cout, Cin, self.wws, S=S, xf=rec.xf_in)
         if not need_gx:
             return None
         gx = torch.empty(x.shape, dtype=dt, device=dev)
@@ -259,11 +262,11 @@ class Engine:
         return gx
 
     # ------------------------------------------------------------------ DoubleResNet
-    def double_fwd(self, dbl, x, out, training, dt):
+    def double_fwd(self, dbl, x, out, training, dt, xf_in=None):
         N, H, W, _ = x.shape
         S = dbl.res1.stride
         mid = torch.empty((N, out.shape[1], out.shape[2], out.shape[3]), dtype=dt, device=x.device)
-        r1 = self.block_fwd(dbl.res1, x, mid, training, dt)
+        r1 = self.block_fwd(dbl.res1, x, mid, training, dt, xf_in)
         r2 = self.block_fwd(dbl.res2, mid, out, training, dt)
         return (r1, r2) if self._save else None
 
@@ -273,27 +276,30 @@ class Engine:
         return self.block_bwd(r1, g_mid, None, G, need_gx)
 
     # ------------------------------------------------------------------ ConvTransposeLayer
-    def deconv_fwd(self, dl, x, cat, Cd, dt):
+    def deconv_fwd(self, dl, x, cat, Cd, dt, xf_x=None):
         """ConvTranspose2d(k4,s2,p1) of x into channels [0,Cd) of the concat buffer (4 output phases)."""
         wp = self.packed(dl.deconv.weight, dt, "tfwd")
         up = cat[..., :Cd]
         for ry in range(2):
             for rx in range(2):
-                ops.conv(x, wp, _phase(up, ry, rx), ops.transposed_phase_taps(4, 1, 1, 2, ry, rx), Cd)
+                ops.conv(x, wp, _phase(up, ry, rx), ops.transposed_phase_taps(4, 1, 1, 2, ry, rx), Cd, xf=xf_x)
 
-    def declayer_fwd(self, dl, x, cat, Cd, out, training, dt):
-        """ConvTransposeLayer.forward (models/common_layers.py:127-132); the skip half of `cat` is already filled."""
-        self.deconv_fwd(dl, x, cat, Cd, dt)
-        recs = self.double_fwd(dl.res, cat, out, training, dt)
+    def declayer_fwd(self, dl, x, cat, Cd, out, training, dt, xf_x=None, xf_cat=None):
+        """ConvTransposeLayer.forward (models/common_layers.py:127-132); the skip half of `cat` is already filled.
+        xf_x / xf_cat: affines of a virtual deconv input / virtual skip channels (ASPP_ResNet)."""
+        self.deconv_fwd(dl, x, cat, Cd, dt, xf_x)
+        recs = self.double_fwd(dl.res, cat, out, training, dt, xf_cat)
         if not self._save:
             return None
         rec = Saved()
-        rec.dl, rec.x, rec.cat, rec.Cd, rec.recs = dl, x, cat, Cd, recs
+        rec.dl, rec.x, rec.cat, rec.Cd, rec.recs, rec.xf_x = dl, x, cat, Cd, recs, xf_x
         return rec
 
     def declayer_bwd(self, rec, go, G, xf_x: Optional[Affine] = None):
-        """returns (g_x, g_cat); g_cat[..., Cd:] is the gradient of the skip tensor"""
+        """returns (g_x, g_cat); g_cat[..., Cd:] is the gradient of the skip tensor (w.r.t. the transformed
+        values when the layer was given affines)"""
         dl, x, cat, Cd = rec.dl, rec.x, rec.cat, rec.Cd
+        xf_x = rec.xf_x if xf_x is None else xf_x
         g_cat = self.double_bwd(rec.recs, go, None, G)
         g_up = g_cat[..., :Cd]
         Cin = x.shape[3]
@@ -344,6 +350,271 @@ class Engine:
         red = ops.stat_buffer(Cout, g_c0.device)
         ops.channel_sum(g_c0, red)
         ops.cast_f64_to_f32(red, G(conv1.bias), Cout)
+
+
+    # ------------------------------------------------------------------ head (shared by both networks)
+    def head_fwd(self, m, d1o, training, dt):
+        N, H, W, _ = d1o.shape
+        bn10 = self.bn(m.bn10)
+        nk = m.conv10.out_channels
+        c10 = torch.empty((N, H, W, nk), dtype=dt, device=d1o.device)
+        ops.conv(d1o, self.packed(m.conv10.weight, dt, "fwd"), c10, T7, nk, bias=m.conv10.bias, stats=bn10.stats)
+        self._finish_bn(bn10, N * H * W, training)
+        ncls = m.conv11.out_channels
+        out = torch.empty((N, ncls, H, W), dtype=torch.float32, device=d1o.device)
+        ops.conv(c10, self.packed(m.conv11.weight, dt, "fwd"), out, T7, ncls, xf=self.relu_affine(bn10),
+                 bias=m.conv11.bias, logsoftmax=True)
+        return c10, out
+
+    def head_bwd(self, m, sv, g_logp, G):
+        dt, dev = sv.dt, sv.x.device
+        N, ncls, H, W = sv.out.shape
+        ip = m.conv10.in_channels
+        g_l = torch.empty((N, H, W, 16), dtype=dt, device=dev)
+        ops.logsoftmax_bwd(g_logp, sv.out, g_l)
+        bn10 = self.bn(m.bn10)
+        nk = m.conv10.out_channels
+        ops.wgrad(sv.c10, g_l, T7, G(m.conv11.weight), nk * 49, 49, ncls, nk, self.wws, xf=self.relu_affine(bn10))
+        NS = L.STAT_SLOTS
+        red = ops.stat_buffer(16 + nk, dev)
+        ops.channel_sum(g_l, red[:16 * NS])
+        ops.cast_f64_to_f32(red[:16 * NS], G(m.conv11.bias), ncls, stride=16)
+        g_a10 = torch.empty((N, H, W, nk), dtype=dt, device=dev)
+        ops.conv(g_l, self._packed_dgrad_padded(m.conv11.weight, dt), g_a10, DG7, nk)
+        del g_l
+        g_c10 = self._bn_bwd(bn10, g_a10, None, sv.c10, True, G, N * H * W)
+        del g_a10
+        ops.wgrad(sv.d1o, g_c10, T7, G(m.conv10.weight), ip * 49, 49, nk, ip, self.wws)
+        ops.channel_sum(g_c10, red[16 * NS:])
+        ops.cast_f64_to_f32(red[16 * NS:], G(m.conv10.bias), nk)
+        g = torch.empty(sv.d1o.shape, dtype=dt, device=dev)
+        self._conv_dgrad(m.conv10, g_c10, g, 1, k=7)
+        return g
+
+    def _check_input(self, x, cin):
+        L.require_cuda(x, "input")
+        if x.dtype != torch.float32:
+            raise RuntimeError("ubresnet_amd: input must be float32 NCHW (got %s)" % x.dtype)
+        if x.dim() != 4 or x.shape[1] != cin:
+            raise RuntimeError("ubresnet_amd: expected input [B,%d,H,W], got %s" % (cin, tuple(x.shape)))
+        if x.shape[2] % 32 or x.shape[3] % 32:
+            raise RuntimeError("ubresnet_amd: H and W must be multiples of 32 (ConvTranspose2d output_size contract of the "
+                               "reference, models/common_layers.py:128); got %dx%d" % (x.shape[2], x.shape[3]))
+        return x if x.is_contiguous() else x.contiguous()
+
+    def _grad_views(self, dev):
+        flat = torch.empty(self.grad_numel, dtype=torch.float32, device=dev)
+        views = {}
+        for name, p in self.grad_order:
+            o = self.grad_offsets[name]
+            views[id(p)] = flat[o:o + p.numel()].view(p.shape)
+        return flat, views
+
+    def _stage_notifier(self, flat, grad_ready):
+        done = [0]
+        ids = [id(p) for _, p in self.grad_order]
+
+        def stage_done(last_param):
+            if grad_ready is None:
+                return
+            i = ids.index(id(last_param))
+            hi = self.grad_offsets[self.grad_order[i][0]] + (self.grad_order[i][1].numel() + 3) // 4 * 4
+            if hi > done[0]:
+                grad_ready(flat, done[0], hi)
+                done[0] = hi
+        return stage_done
+
+    # ------------------------------------------------------------------ ASPP_ResNet (models/ASPP_ResNet.py:416-523)
+    def _affine_arena(self, sv, device, sizes, relu_ranges):
+        """per-pass [4][T] float arena of per-channel affines: identity (sub 0, scale 1, shift 0, lo -inf) except
+        lo = 0 on `relu_ranges` (where BatchNorm+ReLU sites will be bound).  One template copy per pass."""
+        T = sum(sizes)
+        key = (device, tuple(sizes), tuple(relu_ranges))
+        tmpl = self._const.get(key)
+        if tmpl is None:
+            tmpl = torch.zeros((4, T), dtype=torch.float32, device=device)
+            tmpl[1].fill_(1.0)
+            tmpl[3].fill_(ops.NEG_BIG)
+            for lo, hi in relu_ranges:
+                tmpl[3, lo:hi].zero_()
+            self._const[key] = tmpl
+        arena = torch.empty_like(tmpl)
+        arena.copy_(tmpl)
+        sv.arena = arena
+        offs, o = [], 0
+        for n in sizes:
+            offs.append(o)
+            o += n
+        return arena, offs
+
+    def _bind_site(self, site, arena, off):
+        """BatchNorm+ReLU site whose vectors live at arena[:, off:off+C]"""
+        Cn = site.C
+        site.mean, site.scale, site.shift = arena[0, off:off + Cn], arena[1, off:off + Cn], arena[2, off:off + Cn]
+
+    def _arena_affine(self, arena, off, n):
+        return Affine(arena[0, off:off + n], arena[1, off:off + n], arena[2, off:off + n], arena[3, off:off + n])
+
+    def aspp_level_fwd(self, layer, post, e, cpost, arena, off_acat, training, dt):
+        """ASPP.forward + ASPP_post.forward (models/ASPP_ResNet.py:227-263,280-286).  e: encoder output view
+        [N,h,w,C]; cpost: destination view of the RAW 1x1 output (its BN+ReLU is folded into consumers)."""
+        N, h, w, Cn = e.shape
+        acat = torch.empty((N, h, w, 64 + Cn), dtype=dt, device=e.device)
+        cnt = N * h * w
+        for b, (conv, bn, k, dil) in enumerate(layer.branches()):
+            site = self.bn(bn)
+            ops.conv(e, self.packed(conv.weight, dt, "fwd"), acat[..., 16 * b:16 * b + 16], ops.conv_taps(k, dil, dil * (k // 2)),
+                     16, bias=conv.bias, stats=site.stats)
+            self._finish_bn(site, cnt, training)
+        ops.maxpool_fwd(e, None, acat[..., 64:], None, 1)
+        psite = self.bn(post.ASPP_bn)
+        xf = self._arena_affine(arena, off_acat, 64 + Cn)
+        ops.conv(acat, self.packed(post.ASPP_conv.weight, dt, "fwd"), cpost, T1, Cn, xf=xf, bias=post.ASPP_conv.bias, stats=psite.stats)
+        self._finish_bn(psite, cnt, training)
+        if not self._save:
+            return None
+        rec = Saved()
+        rec.layer, rec.post, rec.e, rec.cpost, rec.acat, rec.xf = layer, post, e, cpost, acat, xf
+        return rec
+
+    def aspp_level_bwd(self, rec, g_post, g_base, G):
+        """g_post: gradient w.r.t. relu(bn(cpost)) (a slice of the consumer's input gradient); g_base: gradient
+        already owed to e through the direct skip (accumulated into the result).  Returns the ASPP's total g_e."""
+        layer, post, e, cpost, acat = rec.layer, rec.post, rec.e, rec.cpost, rec.acat
+        N, h, w, Cn = e.shape
+        dt, dev, cnt = e.dtype, e.device, N * h * w
+        psite = self.bn(post.ASPP_bn)
+        g_cpost = self._bn_bwd(psite, g_post, None, cpost, True, G, cnt)
+        ops.wgrad(acat, g_cpost, T1, G(post.ASPP_conv.weight), 64 + Cn, 1, Cn, 64 + Cn, self.wws, xf=rec.xf)
+        red = ops.stat_buffer(Cn, dev)
+        ops.channel_sum(g_cpost, red)
+        ops.cast_f64_to_f32(red, G(post.ASPP_conv.bias), Cn)
+        g_acat = torch.empty(acat.shape, dtype=dt, device=dev)
+        ops.conv(g_cpost, self.packed(post.ASPP_conv.weight, dt, "dgrad"), g_acat, DG1, 64 + Cn)
+        del g_cpost
+        g_e = torch.empty(e.shape, dtype=dt, device=dev)
+        ops.maxpool_bwd(e, None, g_acat[..., 64:], g_base, g_e, 1)
+        for b, (conv, bn, k, dil) in enumerate(layer.branches()):
+            site = self.bn(bn)
+            g_cb = self._bn_bwd(site, g_acat[..., 16 * b:16 * b + 16], None, acat[..., 16 * b:16 * b + 16], True, G, cnt)
+            kk = k * k
+            taps = ops.conv_taps(k, dil, dil * (k // 2))
+            ops.wgrad(e, g_cb, taps, G(conv.weight), Cn * kk, kk, 16, Cn, self.wws)
+            redb = ops.stat_buffer(16, dev)
+            ops.channel_sum(g_cb, redb)
+            ops.cast_f64_to_f32(redb, G(conv.bias), 16)
+            ops.conv(g_cb, self.packed(conv.weight, dt, "dgrad"), g_e, ops.conv_dgrad_taps_s1(k, dil, dil * (k // 2)), Cn, addend=g_e)
+        return g_e
+
+    def aspp_forward(self, x, training, dt, save):
+        m = self.model
+        self._save = save
+        if save and not training:
+            raise RuntimeError("ubresnet_amd: gradients through eval-mode BatchNorm are not supported; "
+                               "call model.train() or wrap inference in torch.no_grad()")
+        x = self._check_input(x, m.conv1.in_channels)
+        N, Cin, H, W = x.shape
+        dev, ip = x.device, m.inplanes
+        sv = Saved()
+        self._alloc_pass_workspaces(sv, dev, training)
+        E = lambda *shape: torch.empty(shape, dtype=dt, device=dev)
+        C3, C4, C5 = 8 * ip, 16 * ip, 32 * ip
+        # affine arena: [acat3 | acat4 | acat5 | cat4 (up,post3,e3) | cat5 (up,post4,e4) | skip5 (post5,e5)]
+        sizes = [64 + C3, 64 + C4, 64 + C5, C3 + 2 * C3, C4 + 2 * C4, 2 * C5]
+        o, offs0 = 0, []
+        for n in sizes:
+            offs0.append(o)
+            o += n
+        relu_ranges = [(offs0[0], offs0[0] + 64), (offs0[1], offs0[1] + 64), (offs0[2], offs0[2] + 64),
+                       (offs0[3] + C3, offs0[3] + 2 * C3), (offs0[4] + C4, offs0[4] + 2 * C4), (offs0[5], offs0[5] + C5)]
+        arena, offs = self._affine_arena(sv, dev, sizes, relu_ranges)
+        for lvl, o_acat in ((3, offs[0]), (4, offs[1]), (5, offs[2])):
+            layer = getattr(m, "ASPP_layer_enc%d" % lvl)
+            for b, (_, bn, _, _) in enumerate(layer.branches()):
+                self._bind_site(self.bn(bn), arena, o_acat + 16 * b)
+        self._bind_site(self.bn(m.ASPP_combine_enc3.ASPP_bn), arena, offs[3] + C3)
+        self._bind_site(self.bn(m.ASPP_combine_enc4.ASPP_bn), arena, offs[4] + C4)
+        self._bind_site(self.bn(m.ASPP_combine_enc5.ASPP_bn), arena, offs[5])
+        sv.sites = [(s, s.scale, s.shift, s.mean, s.invstd) for s in self.bn_sites]
+
+        bn1 = self.bn(m.bn1)
+        c0 = E(N, H, W, ip)
+        x16 = self.stem_fwd(m.conv1, x, c0, bn1.stats, dt)
+        self._finish_bn(bn1, N * H * W, training)
+        cat1 = E(N, H, W, 2 * ip)
+        p0 = E(N, H // 2, W // 2, ip)
+        ops.maxpool_fwd(c0, self.relu_affine(bn1), p0, cat1[..., ip:], 2)
+        cat2 = E(N, H // 2, W // 2, 4 * ip)
+        cat3 = E(N, H // 4, W // 4, 8 * ip)
+        cat4 = E(N, H // 8, W // 8, 3 * C3)
+        cat5 = E(N, H // 16, W // 16, 3 * C4)
+        skip5 = E(N, H // 32, W // 32, 2 * C5)
+        e1, e2 = cat2[..., 2 * ip:], cat3[..., 4 * ip:]
+        e3, e4, e5 = cat4[..., 2 * C3:], cat5[..., 2 * C4:], skip5[..., C5:]
+        r1 = self.double_fwd(m.enc_layer1, p0, e1, training, dt)
+        r2 = self.double_fwd(m.enc_layer2, e1, e2, training, dt)
+        r3 = self.double_fwd(m.enc_layer3, e2, e3, training, dt)
+        r4 = self.double_fwd(m.enc_layer4, e3, e4, training, dt)
+        r5 = self.double_fwd(m.enc_layer5, e4, e5, training, dt)
+        a3 = self.aspp_level_fwd(m.ASPP_layer_enc3, m.ASPP_combine_enc3, e3, cat4[..., C3:2 * C3], arena, offs[0], training, dt)
+        a4 = self.aspp_level_fwd(m.ASPP_layer_enc4, m.ASPP_combine_enc4, e4, cat5[..., C4:2 * C4], arena, offs[1], training, dt)
+        a5 = self.aspp_level_fwd(m.ASPP_layer_enc5, m.ASPP_combine_enc5, e5, skip5[..., :C5], arena, offs[2], training, dt)
+
+        d5o = E(N, H // 16, W // 16, 32 * ip)
+        d5 = self.declayer_fwd(m.dec_layer5, skip5, cat5, C4, d5o, training, dt,
+                               xf_x=self._arena_affine(arena, offs[5], 2 * C5), xf_cat=self._arena_affine(arena, offs[4], 3 * C4))
+        d4o = E(N, H // 8, W // 8, 16 * ip)
+        d4 = self.declayer_fwd(m.dec_layer4, d5o, cat4, C3, d4o, training, dt, xf_cat=self._arena_affine(arena, offs[3], 3 * C3))
+        d3o = E(N, H // 4, W // 4, 4 * ip)
+        d3 = self.declayer_fwd(m.dec_layer3, d4o, cat3, 4 * ip, d3o, training, dt)
+        d2o = E(N, H // 2, W // 2, 2 * ip)
+        d2 = self.declayer_fwd(m.dec_layer2, d3o, cat2, 2 * ip, d2o, training, dt)
+        d1o = E(N, H, W, ip)
+        d1 = self.declayer_fwd(m.dec_layer1, d2o, cat1, ip, d1o, training, dt)
+        c10, out = self.head_fwd(m, d1o, training, dt)
+        if not save:
+            return out, None
+        sv.x, sv.x16, sv.c0 = x, x16, c0
+        sv.enc, sv.aspp, sv.dec = (r1, r2, r3, r4, r5), (a3, a4, a5), (d1, d2, d3, d4, d5)
+        sv.d1o, sv.c10, sv.out, sv.dt = d1o, c10, out, dt
+        return out, sv
+
+    def aspp_backward(self, sv, g_logp, grad_ready=None):
+        m = self.model
+        dt, dev = sv.dt, sv.x.device
+        self._rebind(sv)
+        flat, views = self._grad_views(dev)
+        G = lambda p: views[id(p)]
+        stage_done = self._stage_notifier(flat, grad_ready)
+        N, ncls, H, W = sv.out.shape
+        ip = m.inplanes
+        C3, C4, C5 = 8 * ip, 16 * ip, 32 * ip
+        if not g_logp.is_contiguous():
+            g_logp = g_logp.contiguous()
+        g = self.head_bwd(m, sv, g_logp, G); stage_done(m.bn10.bias)
+        d1, d2, d3, d4, d5 = sv.dec
+        g, gc1 = self.declayer_bwd(d1, g, G); stage_done(m.dec_layer1.deconv.weight)
+        g, gc2 = self.declayer_bwd(d2, g, G); stage_done(m.dec_layer2.deconv.weight)
+        g, gc3 = self.declayer_bwd(d3, g, G); stage_done(m.dec_layer3.deconv.weight)
+        g, gc4 = self.declayer_bwd(d4, g, G); stage_done(m.dec_layer4.deconv.weight)
+        gs5, gc5 = self.declayer_bwd(d5, g, G); stage_done(m.dec_layer5.deconv.weight)
+        r1, r2, r3, r4, r5 = sv.enc
+        a3, a4, a5 = sv.aspp
+        g_e5 = self.aspp_level_bwd(a5, gs5[..., :C5], gs5[..., C5:], G)
+        g = self.double_bwd(r5, g_e5, None, G); stage_done(m.enc_layer5.res1.conv1.weight)
+        g_e4 = self.aspp_level_bwd(a4, gc5[..., C4:2 * C4], gc5[..., 2 * C4:], G)
+        g = self.double_bwd(r4, g, g_e4, G); stage_done(m.enc_layer4.res1.conv1.weight)
+        g_e3 = self.aspp_level_bwd(a3, gc4[..., C3:2 * C3], gc4[..., 2 * C3:], G)
+        g = self.double_bwd(r3, g, g_e3, G); stage_done(m.enc_layer3.res1.conv1.weight)
+        g = self.double_bwd(r2, g, gc3[..., 4 * ip:], G); stage_done(m.enc_layer2.res1.conv1.weight)
+        g = self.double_bwd(r1, g, gc2[..., 2 * ip:], G); stage_done(m.enc_layer1.res1.conv1.weight)
+        bn1 = self.bn(m.bn1)
+        g_x0 = torch.empty(sv.c0.shape, dtype=dt, device=dev)
+        ops.maxpool_bwd(sv.c0, self.relu_affine(bn1), g, gc1[..., ip:], g_x0, 2)
+        g_c0 = self._bn_bwd(bn1, g_x0, None, sv.c0, True, G, N * H * W)
+        self.stem_bwd(m.conv1, sv.x16, g_c0, G)
+        stage_done(self.grad_order[-1][1])
+        return flat, views
 
     # ------------------------------------------------------------------ UResNet
     def uresnet_forward(self, x: torch.Tensor, training: bool, dt: torch.dtype, save: bool):
@@ -521,9 +792,13 @@ class Engine:
     def forward(self, x, training, dt, save):
         if self.kind == "uresnet":
             return self.uresnet_forward(x, training, dt, save)
+        if self.kind == "aspp":
+            return self.aspp_forward(x, training, dt, save)
         raise RuntimeError("ubresnet_amd: unknown network kind %r" % self.kind)
 
     def backward(self, sv, g_out, grad_ready=None):
         if self.kind == "uresnet":
             return self.uresnet_backward(sv, g_out, grad_ready)
+        if self.kind == "aspp":
+            return self.aspp_backward(sv, g_out, grad_ready)
         raise RuntimeError("ubresnet_amd: unknown network kind %r" % self.kind)
