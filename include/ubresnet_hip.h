@@ -240,6 +240,20 @@ int ubr_channel_sum(int dtype, int64_t npix, int C, const void* g, int64_t g_ps,
 int ubr_cast_f64_to_f32(const double* src, int stride, int slots, float* dst, int n, double scale, int accumulate, void* stream);
 int ubr_zero(void* p, int64_t bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Whole-view tiling (deploy/run_ubresnet_wholeview.py:191-277 slices (bs,1,512,832) crops out of
+ * [3,1,rows,cols] plane images and stitches the network output back).  tile_desc_host is an
+ * int32 [ntiles][7] HOST array {plane, row0, col0, keep_r0, keep_r1, keep_c0, keep_c1}: the tile
+ * covers view[plane][row0:row0+th][col0:col0+tw]; when stitching, tile pixels inside the keep
+ * window (tile coordinates) are written to out[plane][c][row0+y][col0+x].  Keep windows of a
+ * tiling partition the view, so every output pixel has exactly one writer.
+ * ---------------------------------------------------------------------------------------- */
+#define UBR_MAX_TILES 64
+int ubr_crop_tiles(const float* view /*[P][rows][cols]*/, int P, int rows, int cols, const int32_t* tile_desc_host, int ntiles,
+                   int th, int tw, float* out /*[ntiles][1][th][tw]*/, void* stream);
+int ubr_stitch_tiles(const float* scores /*[ntiles][C][th][tw]*/, int C, int th, int tw, const int32_t* tile_desc_host, int ntiles,
+                     float* out /*[P][C][rows][cols]*/, int P, int rows, int cols, void* stream);
+
 const char* ubr_last_error(void);
 int ubr_version(void);
 

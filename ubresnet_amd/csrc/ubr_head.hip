@@ -5,6 +5,9 @@
 // (training/train_ubresnet2018_wlarcv2.py:509-566).
 #include "ubr_common.h"
 #include "ubr_host.h"
+#ifndef UBR_MAX_TILES
+#define UBR_MAX_TILES 64
+#endif
 
 namespace {
 
@@ -422,6 +425,76 @@ extern "C" int ubr_confusion(const float* logp_nchw, const int64_t* target, int 
   hipLaunchKernelGGL(confusion_kernel, dim3((unsigned)blocks), dim3(256), (size_t)C * C * sizeof(unsigned), (hipStream_t)stream,
                      logp_nchw, (const long long*)target, N, C, hw, cm);
   UBR_LAUNCH_CHECK("ubr_confusion");
+  return UBR_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// whole-view tiling (shape of deploy/run_ubresnet_wholeview.py:191-277): crop overlapping tiles out of
+// the plane images into a batch, and stitch per-tile class scores back, each output pixel taken
+// from exactly one tile (its keep-window), so the result does not depend on launch order.
+// ------------------------------------------------------------------------------------------
+struct TileK {
+  int ntiles, th, tw, rows, cols, C;
+  int plane[UBR_MAX_TILES], r0[UBR_MAX_TILES], c0[UBR_MAX_TILES];
+  int kr0[UBR_MAX_TILES], kr1[UBR_MAX_TILES], kc0[UBR_MAX_TILES], kc1[UBR_MAX_TILES];   // keep window, tile coordinates
+};
+__global__ __launch_bounds__(256) void crop_tiles_kernel(const float* view, float* out, const TileK k) {
+  const int t = blockIdx.y;
+  const long n = (long)k.th * k.tw;
+  const float* src = view + (long)k.plane[t] * k.rows * k.cols;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int y = (int)(i / k.tw), x = (int)(i % k.tw);
+    const int sy = k.r0[t] + y, sx = k.c0[t] + x;
+    out[(long)t * n + i] = (sy < k.rows && sx < k.cols) ? src[(long)sy * k.cols + sx] : 0.f;
+  }
+}
+__global__ __launch_bounds__(256) void stitch_tiles_kernel(const float* scores, float* out, const TileK k) {
+  const int t = blockIdx.y;
+  const int kh = k.kr1[t] - k.kr0[t], kw = k.kc1[t] - k.kc0[t];
+  const long n = (long)k.C * kh * kw;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int x = (int)(i % kw);
+    const long r = i / kw;
+    const int y = (int)(r % kh), c = (int)(r / kh);
+    const int ty = k.kr0[t] + y, tx = k.kc0[t] + x;
+    const int oy = k.r0[t] + ty, ox = k.c0[t] + tx;
+    if (oy < k.rows && ox < k.cols)
+      out[(((long)k.plane[t] * k.C + c) * k.rows + oy) * k.cols + ox] = scores[(((long)t * k.C + c) * k.th + ty) * k.tw + tx];
+  }
+}
+static int fill_tilek(TileK& k, const int32_t* desc, int ntiles, int th, int tw, int rows, int cols, int C, int P, bool keep) {
+  UBR_CHECK(desc && ntiles >= 1 && ntiles <= UBR_MAX_TILES && th > 0 && tw > 0 && rows > 0 && cols > 0 && C >= 1 && P >= 1,
+            "ubr tiles: bad arguments (ntiles=%d)", ntiles);
+  k.ntiles = ntiles; k.th = th; k.tw = tw; k.rows = rows; k.cols = cols; k.C = C;
+  for (int t = 0; t < ntiles; ++t) {
+    const int32_t* d = desc + 7 * t;
+    UBR_CHECK(d[0] >= 0 && d[0] < P && d[1] >= 0 && d[2] >= 0 && d[1] < rows && d[2] < cols, "ubr tiles: tile %d origin out of range", t);
+    k.plane[t] = d[0]; k.r0[t] = d[1]; k.c0[t] = d[2];
+    if (keep) {
+      UBR_CHECK(d[3] >= 0 && d[3] <= d[4] && d[4] <= th && d[5] >= 0 && d[5] <= d[6] && d[6] <= tw, "ubr tiles: tile %d keep window out of range", t);
+      k.kr0[t] = d[3]; k.kr1[t] = d[4]; k.kc0[t] = d[5]; k.kc1[t] = d[6];
+    }
+  }
+  return UBR_OK;
+}
+extern "C" int ubr_crop_tiles(const float* view, int P, int rows, int cols, const int32_t* tile_desc_host, int ntiles,
+                              int th, int tw, float* out, void* stream) {
+  UBR_CHECK(view && out, "ubr_crop_tiles: null pointer");
+  TileK k{};
+  int rc = fill_tilek(k, tile_desc_host, ntiles, th, tw, rows, cols, 1, P, false);
+  if (rc != UBR_OK) return rc;
+  hipLaunchKernelGGL(crop_tiles_kernel, dim3(ubr_cdiv(th * tw, 256 * 8), ntiles), dim3(256), 0, (hipStream_t)stream, view, out, k);
+  UBR_LAUNCH_CHECK("ubr_crop_tiles");
+  return UBR_OK;
+}
+extern "C" int ubr_stitch_tiles(const float* scores, int C, int th, int tw, const int32_t* tile_desc_host, int ntiles,
+                                float* out, int P, int rows, int cols, void* stream) {
+  UBR_CHECK(scores && out, "ubr_stitch_tiles: null pointer");
+  TileK k{};
+  int rc = fill_tilek(k, tile_desc_host, ntiles, th, tw, rows, cols, C, P, true);
+  if (rc != UBR_OK) return rc;
+  hipLaunchKernelGGL(stitch_tiles_kernel, dim3(ubr_cdiv(C * th * tw, 256 * 8), ntiles), dim3(256), 0, (hipStream_t)stream, scores, out, k);
+  UBR_LAUNCH_CHECK("ubr_stitch_tiles");
   return UBR_OK;
 }
 
