@@ -37,11 +37,15 @@ def test_whole_view_tiling(dtype):
     m = deploy.load_model(None, "cuda:0", num_classes=3, state_dict=sd)
     P, rows, cols, th, tw = 2, 100, 200, 64, 96
     rs = np.random.RandomState(3)
-    view = torch.from_numpy((rs.rand(P, 1, rows, cols) * (rs.rand(P, 1, rows, cols) > 0.9) * 100).astype(np.float32)).cuda()
+    # random (untrained) weights with eval-mode running statistics do not normalise the activations, so keep the
+    # fp16 case inside the fp16 range with a small input scale
+    amp = 100.0 if dtype == torch.float32 else 0.5
+    view = torch.from_numpy((rs.rand(P, 1, rows, cols) * (rs.rand(P, 1, rows, cols) > 0.9) * amp).astype(np.float32)).cuda()
     seg = deploy.WholeViewSegmenter(m, rows, cols, planes=P, tile=(th, tw), batch=4, dtype=dtype, use_graph=True)
     ro, co = deploy.regular_tiling(rows, cols, th, tw)
     assert ro == [0, 36] and co == [0, 52, 104]
     out = seg(view)
+    assert torch.isfinite(out).all()
     out2 = seg(view)                      # graph replay is repeatable
     assert torch.equal(out, out2)
     eager = deploy.WholeViewSegmenter(m, rows, cols, planes=P, tile=(th, tw), batch=4, dtype=dtype, use_graph=False)
