@@ -184,11 +184,13 @@ def main():
                          "achieved_TFLOPs_per_gpu": MODEL_FLOP_PER_IMG * (a.size * a.size / 262144.0) * a.batch * a.steps / el / 1e12}
 
     # ---- per-launch breakdown of one more step (HIP events on the launch stream) -> roofline of the dominant kernel
-    if rank == 0 and not a.no_breakdown:
-        prof = ops.LaunchProfiler()
+    if not a.no_breakdown:
+        prof = ops.LaunchProfiler() if rank == 0 else None
         ops._prof = prof
-        step()
+        step()                      # every rank runs it: the step contains the gradient all-reduce
         ops._prof = None
+        torch.cuda.synchronize()
+    if rank == 0 and not a.no_breakdown:
         agg = prof.summary()
         rows = sorted(((v[1], k, v) for k, v in agg.items()), reverse=True)
         tot = sum(r[0] for r in rows)

@@ -1,0 +1,107 @@
+"""Data-parallel path on the GPU box: two ranks (gloo rendezvous on 127.0.0.1, both on cuda:0) run the real
+train step on their shards of the global batch; after GradAllReducer.finish() every rank's .grad tensors are
+the mean of the per-shard gradients (BatchNorm statistics local to the shard, as nn.DataParallel in
+training/train_ubresnet2018_wlarcv2.py:99-103), and the .grad tensors alias the flat buffer that was reduced."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from oracle import uresnet_oracle as O
+    from ubresnet_amd import synthetic
+    from ubresnet_amd.dist import GradAllReducer, shard_range
+    from ubresnet_amd.models.ub_uresnet import UResNet
+    from ubresnet_amd.training.pixelwise_nllloss import PixelWiseNLLLoss
+    sd = O.seeded_state_dict(O.uresnet_schema(3, 1, 16, 16), 42)
+    x, lab, wgt = synthetic.make_batch(4, 64, 64, 1000)
+    crit = PixelWiseNLLLoss()
+
+    def local_grads(lo, hi):
+        m = UResNet(3, 1, 16)
+        m.load_state_dict(sd)
+        m = m.cuda().train()
+        loss = crit(m(torch.from_numpy(x[lo:hi]).cuda()), torch.from_numpy(lab[lo:hi]).cuda(), torch.from_numpy(wgt[lo:hi]).cuda())
+        loss.backward()
+        return m, {n: p.grad.clone() for n, p in m.named_parameters()}
+
+    # reference: both shards computed locally, no exchange
+    _, g0 = local_grads(0, 2)
+    _, g1 = local_grads(2, 4)
+    lo, hi = shard_range(4, rank, world)
+    m = UResNet(3, 1, 16)
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    red = GradAllReducer(m, bucket_bytes=8 << 20)
+    loss = crit(m(torch.from_numpy(x[lo:hi]).cuda()), torch.from_numpy(lab[lo:hi]).cuda(), torch.from_numpy(wgt[lo:hi]).cuda())
+    loss.backward()
+    red.finish()
+    torch.cuda.synchronize()
+    flat = m.__dict__["_ubr_flat_grad"]
+    ok, worst = True, 0.0
+    for n, p in m.named_parameters():
+        want = 0.5 * (g0[n] + g1[n])
+        scale = max(want.abs().max().item(), 1e-8)
+        err = (p.grad - want).abs().max().item() / scale
+        worst = max(worst, err)
+        inside = flat.data_ptr() <= p.grad.data_ptr() < flat.data_ptr() + flat.numel() * 4
+        ok = ok and inside and (err <= 1e-5 or want.abs().max().item() < 1e-6)
+    q.put((rank, bool(ok), worst))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_average():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+    print("dp worst rel err per rank", [r[2] for r in res])
+    assert [r[:2] for r in res] == [(0, True), (1, True)]
+
+
+def test_grad_accumulates_like_autograd():
+    sys.path.insert(0, REPO)
+    from oracle import uresnet_oracle as O
+    from ubresnet_amd import synthetic
+    from ubresnet_amd.models.ub_uresnet import UResNet
+    from ubresnet_amd.training.pixelwise_nllloss import PixelWiseNLLLoss
+    sd = O.seeded_state_dict(O.uresnet_schema(3, 1, 16, 16), 42)
+    x, lab, wgt = synthetic.make_batch(1, 64, 64, 1000)
+    m = UResNet(3, 1, 16)
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    crit = PixelWiseNLLLoss()
+    args = (torch.from_numpy(lab).cuda(), torch.from_numpy(wgt).cuda())
+    crit(m(torch.from_numpy(x).cuda()), *args).backward()
+    g1 = {n: p.grad.clone() for n, p in m.named_parameters()}
+    m.bn1.momentum = 0.0          # keep the running stats (they do not enter train-mode outputs anyway)
+    crit(m(torch.from_numpy(x).cuda()), *args).backward()       # no zero_grad: gradients accumulate
+    for n, p in m.named_parameters():
+        assert torch.allclose(p.grad, 2 * g1[n], rtol=1e-5, atol=1e-7), n
+    m.zero_grad()
+    assert all(p.grad is None for p in m.parameters())

@@ -41,8 +41,19 @@ class _NetFn(torch.autograd.Function):
         flat, views = ctx.eng.backward(ctx.sv, g_out, hook)
         ctx.sv = None
         ctx.model.__dict__["_ubr_flat_grad"] = flat
-        grads = tuple(views[id(p)] if p.requires_grad else None for p in ctx.params)
-        return (None, None, None, None) + grads
+        # Parameter gradients are installed directly as views of the flat buffer (zero copy, and the
+        # data-parallel all-reduce of `flat` IS the all-reduce of every .grad).  Handing them to autograd's
+        # AccumulateGrad instead would clone each of the 165 tensors (it only steals unreferenced tensors).
+        # Accumulation semantics are kept: an existing .grad is added to, never overwritten.
+        for p in ctx.params:
+            if not p.requires_grad:
+                continue
+            g = views[id(p)]
+            if p.grad is None:
+                p.grad = g
+            else:
+                p.grad.add_(g)
+        return (None, None, None, None) + (None,) * len(ctx.params)
 
 
 def run_network(model, kind: str, x: torch.Tensor) -> torch.Tensor:
