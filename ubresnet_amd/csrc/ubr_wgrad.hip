@@ -80,79 +80,88 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgK k) {
       for (int b = 0; b < NBW; ++b) acc[t][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int nb0 = NSPLIT ? wave * NBW : 0;
 
-  constexpr int SB = 4;   // staging batch: loads in flight per thread
+  // ---- staging: each thread keeps ONE channel unit (256 % units-per-pixel == 0), so the BatchNorm constants
+  // of its channels sit in registers.  The tile loop is software-pipelined: the global loads of tile i+1 are
+  // issued into registers (gv/xv) right before the MFMA phase of tile i and written to LDS after it. ----
+  constexpr int GS = (NSPLIT ? 4 : 8) * 32 * UG / 256;       // G slots per thread (TH <= 4 / 8)
+  constexpr int XS = (CPU == 8) ? 12 : (NSPLIT ? 16 : 12);   // X slots per thread (host checks the halo fits)
   float xsub[CPU], xsc[CPU], xsh[CPU], xlo[CPU];
   if (has_xf) {
     const int ch0 = ci0 + (tid % UX) * CPU;
 #pragma unroll
     for (int e = 0; e < CPU; ++e) { xsub[e] = k.in_sub[ch0 + e]; xsc[e] = k.in_scale[ch0 + e]; xsh[e] = k.in_shift[ch0 + e]; xlo[e] = k.in_lo[ch0 + e]; }
   }
+  const int cg = tid % UG, pg0 = tid / UG;
+  constexpr int PGS = 256 / UG;
+  const int cx = tid % UX, px0 = tid / UX;
+  constexpr int PXS_T = 256 / UX;
+  const int npxG = k.TH * 32, npxX = k.HH * k.HW;
+  uint4 gv[GS], xv[XS];
+  unsigned xok = 0u;
 
-  for (int tile = blockIdx.x; tile < k.ntiles; tile += gridDim.x) {
+  auto load_tile = [&](int tile) {
     int tt = tile;
     const int tx = tt % k.tiles_x; tt /= k.tiles_x;
     const int ty = tt % k.tiles_y;
     const int n = tt / k.tiles_y;
     const int oy0 = ty * k.TH, ox0 = tx * 32;
-    __syncthreads();   // previous tile fully consumed
-    // ---- stage gradient tile [TH*32 px][TCO] and input halo [HH*HW px][TCI] ----
-    // Each thread keeps ONE channel unit (256 % units-per-pixel == 0), so the BatchNorm constants of
-    // its channels sit in registers; loads are issued in batches of SB before any LDS store.
-    {
-      const char* gn = k.g + (long)n * k.g_sn;
-      const int cg = tid % UG, pg0 = tid / UG;
-      constexpr int PGS = 256 / UG;
-      const int npx = k.TH * 32;
-      for (int pb = pg0; pb < npx; pb += PGS * SB) {
-        uint4 v[SB];
+    const char* gn = k.g + (long)n * k.g_sn + (long)(co0 + cg * CPU) * ESZ;
 #pragma unroll
-        for (int u = 0; u < SB; ++u) {
-          const int px = pb + u * PGS;
-          const int gy = oy0 + (px >> 5), gx = ox0 + (px & 31);
-          v[u] = make_uint4(0u, 0u, 0u, 0u);
-          if (px < npx && gy < k.GH && gx < k.GW) v[u] = ldg16(gn + (long)gy * k.g_sy + (long)gx * k.g_sx + (long)(co0 + cg * CPU) * ESZ);
-        }
-#pragma unroll
-        for (int u = 0; u < SB; ++u) {
-          const int px = pb + u * PGS;
-          if (px < npx) *reinterpret_cast<uint4*>(gl + px * k.pixbG + cg * 16) = v[u];
-        }
-      }
+    for (int u = 0; u < GS; ++u) {
+      const int px = pg0 + u * PGS;
+      const int gy = oy0 + (px >> 5), gx = ox0 + (px & 31);
+      gv[u] = make_uint4(0u, 0u, 0u, 0u);
+      if (px < npxG && gy < k.GH && gx < k.GW) gv[u] = ldg16(gn + (long)gy * k.g_sy + (long)gx * k.g_sx);
     }
-    {
-      const char* xn = k.x + (long)n * k.x_sn;
-      const int hy0 = oy0 * k.S + k.iy0 + k.dymin, hx0 = ox0 * k.S + k.ix0 + k.dxmin;
-      const int cx = tid % UX, px0 = tid / UX;
-      constexpr int PXS_T = 256 / UX;
-      const int ch0 = ci0 + cx * CPU;
-      const int npx = k.HH * k.HW;
-      for (int pb = px0; pb < npx; pb += PXS_T * SB) {
-        uint4 v[SB];
-        bool ok[SB];
+    const char* xn = k.x + (long)n * k.x_sn + (long)(ci0 + cx * CPU) * ESZ;
+    const int hy0 = oy0 * k.S + k.iy0 + k.dymin, hx0 = ox0 * k.S + k.ix0 + k.dxmin;
+    xok = 0u;
 #pragma unroll
-        for (int u = 0; u < SB; ++u) {
-          const int px = pb + u * PXS_T;
-          const int hy = (int)__umulhi((unsigned)px, k.hw_magic), hx = px - hy * k.HW;
-          const int iy = hy0 + hy, ix = hx0 + hx;
-          ok[u] = px < npx && (unsigned)iy < (unsigned)k.H && (unsigned)ix < (unsigned)k.W;
-          v[u] = make_uint4(0u, 0u, 0u, 0u);
-          if (ok[u]) v[u] = ldg16(xn + (long)iy * k.x_sy + (long)ix * k.x_sx + (long)ch0 * ESZ);
-        }
-#pragma unroll
-        for (int u = 0; u < SB; ++u) {
-          const int px = pb + u * PXS_T;
-          if (has_xf && ok[u]) {
-            float f[CPU];
-            ET<T>::unpack(v[u], f);
-#pragma unroll
-            for (int e = 0; e < CPU; ++e) f[e] = fmaxf(fmaf(f[e] - xsub[e], xsc[e], xsh[e]), xlo[e]);
-            v[u] = ET<T>::pack(f);
-          }
-          if (px < npx) *reinterpret_cast<uint4*>(xl + px * k.pixbX + cx * 16) = v[u];
-        }
-      }
+    for (int u = 0; u < XS; ++u) {
+      const int px = px0 + u * PXS_T;
+      const int hy = (int)__umulhi((unsigned)px, k.hw_magic), hx = px - hy * k.HW;
+      const int iy = hy0 + hy, ix = hx0 + hx;
+      const bool ok = px < npxX && (unsigned)iy < (unsigned)k.H && (unsigned)ix < (unsigned)k.W;
+      xv[u] = make_uint4(0u, 0u, 0u, 0u);
+      if (ok) { xv[u] = ldg16(xn + (long)iy * k.x_sy + (long)ix * k.x_sx); xok |= 1u << u; }
     }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int u = 0; u < GS; ++u) {
+      const int px = pg0 + u * PGS;
+      if (px < npxG) *reinterpret_cast<uint4*>(gl + px * k.pixbG + cg * 16) = gv[u];
+    }
+#pragma unroll
+    for (int u = 0; u < XS; ++u) {
+      const int px = px0 + u * PXS_T;
+      uint4 v = xv[u];
+      if (has_xf && ((xok >> u) & 1u)) {
+        float f[CPU];
+        ET<T>::unpack(v, f);
+#pragma unroll
+        for (int e = 0; e < CPU; ++e) f[e] = fmaxf(fmaf(f[e] - xsub[e], xsc[e], xsh[e]), xlo[e]);
+        v = ET<T>::pack(f);
+      }
+      if (px < npxX) *reinterpret_cast<uint4*>(xl + px * k.pixbX + cx * 16) = v;
+    }
+  };
+
+  // per-tap LDS offsets are wave-uniform: hoist them out of the row loop
+  int toff[TPG];
+#pragma unroll
+  for (int t = 0; t < TPG; ++t)
+    toff[t] = (t0 + t < k.ntaps) ? ((k.dy[t0 + t] - k.dymin) * k.HW + (k.dx[t0 + t] - k.dxmin)) * k.pixbX : 0;
+
+  int tile = blockIdx.x;
+  if (tile < k.ntiles) load_tile(tile);
+  while (tile < k.ntiles) {
+    __syncthreads();     // previous tile fully consumed
+    store_tile();
     __syncthreads();
+    const int next = tile + gridDim.x;
+    if (next < k.ntiles) load_tile(next);      // in flight during the MFMA phase below
+    tile = next;
     // ---- MFMA: K-split: wave takes rows wave, wave+4, ...; N-split: every wave takes every row ----
     for (int r = NSPLIT ? 0 : wave; r < k.TH; r += NSPLIT ? 1 : 4) {
 #pragma unroll
@@ -170,15 +179,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgK k) {
 #pragma unroll
         for (int t = 0; t < TPG; ++t) {
           if (t0 + t < k.ntaps) {
-            const int ddy = k.dy[t0 + t] - k.dymin, ddx = k.dx[t0 + t] - k.dxmin;
 #pragma unroll
             for (int b = 0; b < NBW; ++b) {
               uint4 B;
               if constexpr (CPU == 8) {
-                const char* p = xl + ((r * k.S + ddy) * k.HW + (8 * q + (l16 >> 2)) * k.S + ddx) * k.pixbX + (l16 & 3) * 8 + (nb0 + b) * 32;
+                const char* p = xl + (r * k.S * k.HW + (8 * q + (l16 >> 2)) * k.S) * k.pixbX + toff[t] + (l16 & 3) * 8 + (nb0 + b) * 32;
                 B = tr_frag16(p, 4 * k.S * k.pixbX);
               } else {
-                const char* p = xl + ((r * k.S + ddy) * k.HW + (ks * 16 + 4 * q) * k.S + ddx) * k.pixbX + l16 * 4 + (nb0 + b) * 64;
+                const char* p = xl + (r * k.S * k.HW + (ks * 16 + 4 * q) * k.S) * k.pixbX + toff[t] + l16 * 4 + (nb0 + b) * 64;
                 B = sc_frag32(p, k.S * k.pixbX);
               }
 #pragma unroll
@@ -265,8 +273,19 @@ static int wgrad_plan(const ubr_wgrad_desc* d, WPlan* p) {
     p->TH = d->S == 1 ? 4 : 2;
   }
   p->MA = MA; p->NB = NB; p->TPG = TPG;
-  p->HH = (p->TH - 1) * d->S + 1 + (dymax - dymin);
-  p->HW = 31 * d->S + 1 + (dxmax - dxmin);
+  {
+    // shrink the tile height until the halo fits the per-thread staging registers of the pipelined loop
+    const int cpu = ubr_cpu(d->dtype);
+    const int xs = (cpu == 8) ? 12 : (p->nsplit_mode ? 16 : 12);
+    const int ux = NB * 16 / cpu;
+    for (;;) {
+      p->HH = (p->TH - 1) * d->S + 1 + (dymax - dymin);
+      p->HW = 31 * d->S + 1 + (dxmax - dxmin);
+      if ((long)p->HH * p->HW * ux <= 256L * xs || p->TH == 1) break;
+      p->TH /= 2;
+    }
+    UBR_CHECK((long)p->HH * p->HW * ux <= 256L * xs, "ubr_wgrad: halo of %d x %d pixels x %d units exceeds the staging registers", p->HH, p->HW, ux);
+  }
   p->pixbG = MA * 16 * esz + 16;
   p->pixbX = NB * 16 * esz + 16;
   size_t gbytes = (size_t)p->TH * 32 * p->pixbG;
