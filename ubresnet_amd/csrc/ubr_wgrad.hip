@@ -178,7 +178,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgK k) {
         }
 #pragma unroll
         for (int t = 0; t < TPG; ++t) {
-          if (t0 + t < k.ntaps) {
+          {   // taps beyond ntaps (toff = 0) are computed and discarded: no branch, so the LDS reads of tap t+1
+              // can be issued under the MFMAs of tap t
 #pragma unroll
             for (int b = 0; b < NBW; ++b) {
               uint4 B;
