@@ -273,20 +273,25 @@ static int wgrad_plan(const ubr_wgrad_desc* d, WPlan* p) {
     MA = 4; NB = 4; p->nsplit_mode = 1;
     p->TH = d->S == 1 ? 4 : 2;
   }
-  p->MA = MA; p->NB = NB; p->TPG = TPG;
   {
-    // shrink the tile height until the halo fits the per-thread staging registers of the pipelined loop
+    // the pipelined loop keeps one tile in registers: shrink the tile height, then the channel tile, until the
+    // input halo fits the per-thread staging slots (large dilations / stride 2 / fp32 have the biggest halos)
     const int cpu = ubr_cpu(d->dtype);
-    const int xs = (cpu == 8) ? 12 : (p->nsplit_mode ? 16 : 12);
-    const int ux = NB * 16 / cpu;
+    const int th0 = p->TH;
     for (;;) {
+      const int xs = (cpu == 8) ? 12 : (p->nsplit_mode ? 16 : 12);
+      const int ux = NB * 16 / cpu;
       p->HH = (p->TH - 1) * d->S + 1 + (dymax - dymin);
       p->HW = 31 * d->S + 1 + (dxmax - dxmin);
-      if ((long)p->HH * p->HW * ux <= 256L * xs || p->TH == 1) break;
-      p->TH /= 2;
+      if ((long)p->HH * p->HW * ux <= 256L * xs) break;
+      if (p->TH > 1) { p->TH /= 2; continue; }
+      if (p->nsplit_mode) { p->nsplit_mode = 0; MA = 2; NB = 2; p->TH = d->S == 1 ? 8 : 4; continue; }
+      if (NB > 1) { NB = 1; p->TH = th0 > 4 ? 4 : th0; continue; }
+      ubr_set_error("ubr_wgrad: halo of %d x %d pixels does not fit the staging registers", p->HH, p->HW);
+      return UBR_EINVAL;
     }
-    UBR_CHECK((long)p->HH * p->HW * ux <= 256L * xs, "ubr_wgrad: halo of %d x %d pixels x %d units exceeds the staging registers", p->HH, p->HW, ux);
   }
+  p->MA = MA; p->NB = NB; p->TPG = TPG;
   p->pixbG = MA * 16 * esz + 16;
   p->pixbX = NB * 16 * esz + 16;
   size_t gbytes = (size_t)p->TH * 32 * p->pixbG;
