@@ -35,8 +35,7 @@ struct ConvK {
   int nunits, steps;
   int pixb;                                      // LDS bytes per halo pixel
   unsigned rw, rw_magic;                         // items per halo row and ceil(2^32/rw)
-  int wl_off, halo_off, red_off, xf_off;         // LDS carve offsets
-  int ntiles;                                    // tiles per cout tile (N * tiles_y * tiles_x)
+  int wl_off, halo_off, red_off;                 // LDS carve offsets
   int epilogue;
   int8_t dy[UBR_MAX_TAPS], dx[UBR_MAX_TAPS];
   uint8_t wt[UBR_MAX_TAPS];
@@ -67,11 +66,7 @@ template <> __device__ __forceinline__ void load4<f16_t>(const char* p, float* v
   v[0] = (float)h[0]; v[1] = (float)h[1]; v[2] = (float)h[2]; v[3] = (float)h[3];
 }
 
-// Persistent, software-pipelined workgroup: it walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... and, per tile,
-// the cin blocks; the global loads of stage s+1 (input halo + weight slab) are issued into registers right before
-// the MFMA phase of stage s and written to LDS after it, so HBM/L2 latency hides under compute even at one or
-// two workgroups per CU.  When the layer has a single cin block the weight slab is staged once per workgroup.
-template <typename T, int FW, int NT, int TWF, int HS, int WS>
+template <typename T, int FW, int NT, int TWF>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK k) {
   constexpr int TN = NT * 16;
   constexpr int F = 4 * FW;
@@ -83,15 +78,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK k) {
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* tbl = reinterpret_cast<int*>(smem);
-  float* xfl = reinterpret_cast<float*>(smem + k.xf_off);      // [4][Cin]: sub, scale, shift, lo
   char* wl = smem + k.wl_off;
   char* halo = smem + k.halo_off;
   float* red = reinterpret_cast<float*>(smem + k.red_off);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, l16 = lane & 15;
+  int t = blockIdx.x;
+  const int tx = t % k.tiles_x; t /= k.tiles_x;
+  const int ty = t % k.tiles_y;
+  const int n = t / k.tiles_y;
   const int n0 = blockIdx.y * TN;
-  const bool has_xf = k.in_scale != nullptr;
-  const int Cin = k.CU * CPU;
+  const int oy0 = ty * TH, ox0 = tx * TW;
+  const int hy0 = oy0 * k.S + k.iy0 + k.dymin, hx0 = ox0 * k.S + k.ix0 + k.dxmin;
 
   for (int u = tid; u < 4 * k.steps; u += 256) {
     int off = 0;
@@ -100,11 +98,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK k) {
       off = ((k.dy[tap] - k.dymin) * k.HW + (k.dx[tap] - k.dxmin)) * k.pixb + c * 16;
     }
     tbl[u] = off;
-  }
-  if (has_xf) {
-    for (int i = tid; i < Cin; i += 256) {
-      xfl[i] = k.in_sub[i]; xfl[Cin + i] = k.in_scale[i]; xfl[2 * Cin + i] = k.in_shift[i]; xfl[3 * Cin + i] = k.in_lo[i];
-    }
   }
 
   f32x4 acc[FW][NT];
@@ -121,91 +114,65 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK k) {
     fragbase[i] = ((fr * k.S) * k.HW + fc * 16 * k.S) * k.pixb + l16 * k.S * k.pixb;
   }
 
-  const int nitems = k.HH * (int)k.rw;          // halo items (pixel x unit)
-  const int nwitems = 4 * k.steps * TN;         // weight-slab items
-  const int c = tid & (k.UPB - 1);              // 256 % UPB == 0: a thread's channel unit is fixed
+  const char* xn = k.x + (long)n * k.x_sn;
+  const int nitems = k.HH * (int)k.rw;
+  const bool has_xf = k.in_scale != nullptr;
 
-  uint4 hv[HS], wv[WS];
-  unsigned hok = 0u;
-
-  auto load_stage = [&](int tile, int blk, bool need_w) {
-    int t = tile;
-    const int tx = t % k.tiles_x; t /= k.tiles_x;
-    const int ty = t % k.tiles_y;
-    const int n = t / k.tiles_y;
-    const int hy0 = ty * TH * k.S + k.iy0 + k.dymin, hx0 = tx * TW * k.S + k.ix0 + k.dxmin;
-    const char* xc = k.x + (long)n * k.x_sn + (long)((blk * k.UPB + c) * CPU) * ESZ;
-    hok = 0u;
-#pragma unroll
-    for (int u = 0; u < HS; ++u) {
-      const int i = tid + u * 256;
-      const int hy = (int)__umulhi((unsigned)i, k.rw_magic);
-      const int hx = (i - hy * (int)k.rw) >> k.lgUPB;
-      const int iy = hy0 + hy, ix = hx0 + hx;
-      const bool ok = i < nitems && (unsigned)iy < (unsigned)k.H && (unsigned)ix < (unsigned)k.W;
-      hv[u] = make_uint4(0u, 0u, 0u, 0u);
-      if (ok) { hv[u] = ldg16(xc + (long)iy * k.x_sy + (long)ix * k.x_sx); hok |= 1u << u; }
-    }
-    if (need_w) {
-#pragma unroll
-      for (int u = 0; u < WS; ++u) {
-        const int i = tid + u * 256;
-        const int un = i / TN, nn = i % TN;
-        wv[u] = make_uint4(0u, 0u, 0u, 0u);
-        if (i < nwitems && un < k.nunits) {
-          const int tap = un >> k.lgUPB, cc = un & (k.UPB - 1);
-          wv[u] = ldg16(k.w + ((long)((int)k.wt[tap] * k.CU + blk * k.UPB + cc) * k.Cout_pad + n0 + nn) * 16);
-        }
-      }
-    }
-  };
-  auto store_stage = [&](int blk, bool need_w) {
-    float xsub[CPU], xsc[CPU], xsh[CPU], xlo[CPU];
-    if (has_xf) {
+  for (int blk = 0; blk < k.nblk; ++blk) {
+    if (blk) __syncthreads();
+    // ---- stage the input halo (transform + zero padding) ----
+    // 256 % UPB == 0, so a thread's channel unit c is fixed: its BatchNorm constants are loaded once per
+    // cin block; global loads are issued in batches of SB before any LDS store.
+    {
+      constexpr int SB = 4;
+      const int c = tid & (k.UPB - 1);
       const int ch0 = (blk * k.UPB + c) * CPU;
+      float xsub[CPU], xsc[CPU], xsh[CPU], xlo[CPU];
+      if (has_xf) {
 #pragma unroll
-      for (int e = 0; e < CPU; ++e) { xsub[e] = xfl[ch0 + e]; xsc[e] = xfl[Cin + ch0 + e]; xsh[e] = xfl[2 * Cin + ch0 + e]; xlo[e] = xfl[3 * Cin + ch0 + e]; }
-    }
+        for (int e = 0; e < CPU; ++e) { xsub[e] = k.in_sub[ch0 + e]; xsc[e] = k.in_scale[ch0 + e]; xsh[e] = k.in_shift[ch0 + e]; xlo[e] = k.in_lo[ch0 + e]; }
+      }
+      const char* xc = xn + (long)ch0 * ESZ;
+      for (int ib = tid; ib < nitems; ib += 256 * SB) {
+        uint4 v[SB];
+        int dst[SB];
+        bool ok[SB];
 #pragma unroll
-    for (int u = 0; u < HS; ++u) {
-      const int i = tid + u * 256;
-      if (i < nitems) {
-        const int hy = (int)__umulhi((unsigned)i, k.rw_magic);
-        const int hx = (i - hy * (int)k.rw) >> k.lgUPB;
-        uint4 v = hv[u];
-        if (has_xf && ((hok >> u) & 1u)) {
-          float f[CPU];
-          ET<T>::unpack(v, f);
-#pragma unroll
-          for (int e = 0; e < CPU; ++e) f[e] = fmaxf(fmaf(f[e] - xsub[e], xsc[e], xsh[e]), xlo[e]);
-          v = ET<T>::pack(f);
+        for (int u = 0; u < SB; ++u) {
+          const int i = ib + u * 256;
+          const int hy = (int)__umulhi((unsigned)i, k.rw_magic);
+          const int hx = (i - hy * (int)k.rw) >> k.lgUPB;
+          const int iy = hy0 + hy, ix = hx0 + hx;
+          dst[u] = (hy * k.HW + hx) * k.pixb + c * 16;
+          ok[u] = i < nitems && (unsigned)iy < (unsigned)k.H && (unsigned)ix < (unsigned)k.W;
+          v[u] = make_uint4(0u, 0u, 0u, 0u);
+          if (ok[u]) v[u] = ldg16(xc + (long)iy * k.x_sy + (long)ix * k.x_sx);
         }
-        *reinterpret_cast<uint4*>(halo + (hy * k.HW + hx) * k.pixb + c * 16) = v;
-      }
-    }
-    if (need_w) {
 #pragma unroll
-      for (int u = 0; u < WS; ++u) {
-        const int i = tid + u * 256;
-        if (i < nwitems) *reinterpret_cast<uint4*>(wl + (long)i * 16) = wv[u];
+        for (int u = 0; u < SB; ++u) {
+          if (has_xf && ok[u]) {
+            float f[CPU];
+            ET<T>::unpack(v[u], f);
+#pragma unroll
+            for (int e = 0; e < CPU; ++e) f[e] = fmaxf(fmaf(f[e] - xsub[e], xsc[e], xsh[e]), xlo[e]);
+            v[u] = ET<T>::pack(f);
+          }
+          if (ib + u * 256 < nitems) *reinterpret_cast<uint4*>(halo + dst[u]) = v[u];
+        }
       }
     }
-  };
-
-  int tile = blockIdx.x, blk = 0;
-  bool first = true;
-  if (tile < k.ntiles) load_stage(tile, 0, true);
-  while (tile < k.ntiles) {
-    const bool need_w = first || k.nblk > 1;
-    __syncthreads();                 // LDS free: previous stage's MFMA phase (and epilogue) done; tbl/xfl visible
-    store_stage(blk, need_w);
+    // ---- stage the weight slab: [unit][TN][16 B], zero beyond nunits ----
+    for (int i = tid; i < 4 * k.steps * TN; i += 256) {
+      const int u = i / TN, nn = i % TN;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (u < k.nunits) {
+        const int tap = u >> k.lgUPB, c = u & (k.UPB - 1);
+        v = ldg16(k.w + ((long)((int)k.wt[tap] * k.CU + blk * k.UPB + c) * k.Cout_pad + n0 + nn) * 16);
+      }
+      *reinterpret_cast<uint4*>(wl + (long)i * 16) = v;
+    }
     __syncthreads();
-    first = false;
-    // ---- issue the next stage's global loads, then compute this one ----
-    int ntile = tile, nblk_i = blk + 1;
-    if (nblk_i == k.nblk) { nblk_i = 0; ntile = tile + gridDim.x; }
-    if (ntile < k.ntiles) load_stage(ntile, nblk_i, k.nblk > 1);
-
+    // ---- MFMA over (tap, cin-unit) ----
     for (int s = 0; s < k.steps; ++s) {
       const int off = tbl[4 * s + q];
       uint4 wf[NT];
@@ -219,93 +186,94 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK k) {
         for (int j = 0; j < NT; ++j) acc[i][j] = mma_step<T>(acc[i][j], wf[j], a);
       }
     }
+  }
 
-    if (blk == k.nblk - 1) {
-      // ---------------------------------- epilogue of this tile ----------------------------------
-      int t = tile;
-      const int tx = t % k.tiles_x; t /= k.tiles_x;
-      const int ty = t % k.tiles_y;
-      const int n = t / k.tiles_y;
-      const int oy0 = ty * TH, ox0 = tx * TW;
-      float s1[NT][4], s2[NT][4];
+  // ---------------------------------- epilogue ----------------------------------
+  float bs[NT][4];
 #pragma unroll
-      for (int j = 0; j < NT; ++j)
+  for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { s1[j][r] = 0.f; s2[j][r] = 0.f; }
+    for (int r = 0; r < 4; ++r) {
+      const int ch = n0 + j * 16 + 4 * q + r;
+      bs[j][r] = (k.bias != nullptr && ch < k.Cout) ? k.bias[ch] : 0.f;
+    }
+  float s1[NT][4], s2[NT][4];
 #pragma unroll
-      for (int i = 0; i < FW; ++i) {
-        const int f = wave * FW + i;
-        const int oy = oy0 + f / TWF, ox = ox0 + (f % TWF) * 16 + l16;
-        const bool valid = (oy < k.OH) && (ox < k.OW);
+  for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const int ch = n0 + j * 16 + 4 * q;
-          float v[4];
+    for (int r = 0; r < 4; ++r) { s1[j][r] = 0.f; s2[j][r] = 0.f; }
+
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + ((k.bias != nullptr && ch + r < k.Cout) ? k.bias[ch + r] : 0.f);
-          acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (k.ad != nullptr && valid && ch < k.Cout) {
-            float a4[4];
-            load4<T>(k.ad + (long)n * k.a_sn + (long)oy * k.a_sy + (long)ox * k.a_sx + (long)ch * ESZ, a4);
+  for (int i = 0; i < FW; ++i) {
+    const int f = wave * FW + i;
+    const int oy = oy0 + f / TWF, ox = ox0 + (f % TWF) * 16 + l16;
+    const bool valid = (oy < k.OH) && (ox < k.OW);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += a4[r];
-          }
-          if (k.stats != nullptr && valid) {
+    for (int j = 0; j < NT; ++j) {
+      const int ch = n0 + j * 16 + 4 * q;
+      float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { s1[j][r] += v[r]; s2[j][r] += v[r] * v[r]; }
-          }
-          if (k.epilogue == 0) {
-            if (valid && ch < k.Cout)
-              store4<T>(k.y + (long)n * k.y_sn + (long)oy * k.y_sy + (long)ox * k.y_sx + (long)ch * ESZ, v);
-          } else if (j == 0) {
-            // fused LogSoftmax over the first Cout (<=16) channels, fp32 NCHW output
-            float m = -3.0e38f;
+      for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bs[j][r];
+      if (k.ad != nullptr && valid && ch < k.Cout) {
+        float a4[4];
+        load4<T>(k.ad + (long)n * k.a_sn + (long)oy * k.a_sy + (long)ox * k.a_sx + (long)ch * ESZ, a4);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) if (ch + r < k.Cout) m = fmaxf(m, v[r]);
-            m = fmaxf(m, __shfl_xor(m, 16, 64));
-            m = fmaxf(m, __shfl_xor(m, 32, 64));
-            float e = 0.f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) if (ch + r < k.Cout) e += expf(v[r] - m);
-            e += __shfl_xor(e, 16, 64);
-            e += __shfl_xor(e, 32, 64);
-            const float lse = m + logf(e);
-            if (valid) {
-              float* o = reinterpret_cast<float*>(k.y);
-#pragma unroll
-              for (int r = 0; r < 4; ++r)
-                if (ch + r < k.Cout) o[(((long)n * k.Cout + ch + r) * k.OH + oy) * k.OW + ox] = v[r] - lse;
-            }
-          }
-        }
+        for (int r = 0; r < 4; ++r) v[r] += a4[r];
       }
-      if (k.stats != nullptr) {
+      if (k.stats != nullptr && valid) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int r = 0; r < 4; ++r) { s1[j][r] += v[r]; s2[j][r] += v[r] * v[r]; }
+      }
+      if (k.epilogue == 0) {
+        if (valid && ch < k.Cout)
+          store4<T>(k.y + (long)n * k.y_sn + (long)oy * k.y_sy + (long)ox * k.y_sx + (long)ch * ESZ, v);
+      } else if (j == 0) {
+        // fused LogSoftmax over the first Cout (<=16) channels, fp32 NCHW output
+        float m = -3.0e38f;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float a = wave_quadrow_sum16(s1[j][r]);
-            const float b = wave_quadrow_sum16(s2[j][r]);
-            if (l16 == 0) {
-              red[(wave * TN + j * 16 + 4 * q + r) * 2 + 0] = a;
-              red[(wave * TN + j * 16 + 4 * q + r) * 2 + 1] = b;
-            }
-          }
-        __syncthreads();
-        if (tid < TN) {
-          const int ch = n0 + tid;
-          if (ch < k.Cout) {
-            double a = 0.0, b = 0.0;
+        for (int r = 0; r < 4; ++r) if (ch + r < k.Cout) m = fmaxf(m, v[r]);
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float e = 0.f;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) { a += (double)red[(w * TN + tid) * 2]; b += (double)red[(w * TN + tid) * 2 + 1]; }
-            double* st = k.stats + (size_t)(tile % UBR_STAT_SLOTS) * 2 * k.Cout;
-            atomicAdd(&st[ch], a);
-            atomicAdd(&st[k.Cout + ch], b);
-          }
+        for (int r = 0; r < 4; ++r) if (ch + r < k.Cout) e += expf(v[r] - m);
+        e += __shfl_xor(e, 16, 64);
+        e += __shfl_xor(e, 32, 64);
+        const float lse = m + logf(e);
+        if (valid) {
+          float* o = reinterpret_cast<float*>(k.y);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (ch + r < k.Cout) o[(((long)n * k.Cout + ch + r) * k.OH + oy) * k.OW + ox] = v[r] - lse;
         }
       }
     }
-    tile = ntile; blk = nblk_i;
+  }
+
+  if (k.stats != nullptr) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float a = wave_quadrow_sum16(s1[j][r]);
+        const float b = wave_quadrow_sum16(s2[j][r]);
+        if (l16 == 0) {
+          red[(wave * TN + j * 16 + 4 * q + r) * 2 + 0] = a;
+          red[(wave * TN + j * 16 + 4 * q + r) * 2 + 1] = b;
+        }
+      }
+    __syncthreads();
+    if (tid < TN) {
+      const int ch = n0 + tid;
+      if (ch < k.Cout) {
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { a += (double)red[(w * TN + tid) * 2]; b += (double)red[(w * TN + tid) * 2 + 1]; }
+        double* st = k.stats + (size_t)(blockIdx.x % UBR_STAT_SLOTS) * 2 * k.Cout;
+        atomicAdd(&st[ch], a);
+        atomicAdd(&st[k.Cout + ch], b);
+      }
+    }
   }
 }
 
@@ -325,12 +293,9 @@ static const TileCfg kCfgs[] = {
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
-// per-thread staging slots of the pipelined loop: HS halo items, WS weight items (x 256 threads)
-template <int NT> struct Slots { static constexpr int HS = 10, WS = (NT == 1) ? 13 : (NT == 2 ? 6 : 9); };
-
 template <typename T, int FW, int NT, int TWF>
 int launch_cfg(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
-  auto fn = conv_igemm_kernel<T, FW, NT, TWF, Slots<NT>::HS, Slots<NT>::WS>;
+  auto fn = conv_igemm_kernel<T, FW, NT, TWF>;
   if (lds > 64 * 1024) {
     static thread_local size_t maxset = 0;  // per instantiation
     if (lds > maxset) {
@@ -362,7 +327,7 @@ int launch_T(int cfg, const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
   return UBR_EINVAL;
 }
 
-struct Plan { int cfg; size_t lds; int UPB, steps, HH, HW, pixb, wl_off, halo_off, red_off, xf_off, tiles_x, tiles_y; };
+struct Plan { int cfg; size_t lds; int UPB, steps, HH, HW, pixb, wl_off, halo_off, red_off, tiles_x, tiles_y; };
 
 static bool plan_for(const ubr_conv_desc* d, int cfg, int dymin, int dymax, int dxmin, int dxmax, Plan* p) {
   const TileCfg& c = kCfgs[cfg];
@@ -378,9 +343,6 @@ static bool plan_for(const ubr_conv_desc* d, int cfg, int dymin, int dymax, int 
   const int HW = (TW - 1) * d->S + 1 + (dxmax - dxmin);
   const int pixb = UPB * 16 + 16;
   size_t off = ((size_t)16 * steps + 15) & ~(size_t)15;
-  p->xf_off = (int)off;
-  if (d->xf.scale != nullptr) off += (size_t)4 * d->Cin * sizeof(float);
-  off = (off + 15) & ~(size_t)15;
   p->wl_off = (int)off; off += (size_t)4 * steps * TN * 16;
   p->halo_off = (int)off; off += (size_t)HH * HW * pixb;
   off = (off + 15) & ~(size_t)15;
@@ -388,10 +350,6 @@ static bool plan_for(const ubr_conv_desc* d, int cfg, int dymin, int dymax, int 
   p->cfg = cfg; p->lds = off; p->UPB = UPB; p->steps = steps; p->HH = HH; p->HW = HW; p->pixb = pixb;
   p->tiles_x = ubr_cdiv(d->OW, TW); p->tiles_y = ubr_cdiv(d->OH, TH);
   if ((size_t)HH * HW * UPB >= 60000) return false;   // exact-division bound of the magic multiply
-  // the pipelined loop keeps one stage in registers: halo and weight-slab items must fit the per-thread slots
-  const int hs = 10, ws = (c.NT == 1) ? 13 : (c.NT == 2 ? 6 : 9);
-  if ((size_t)HH * HW * UPB > (size_t)256 * hs) return false;
-  if ((size_t)4 * steps * TN > (size_t)256 * ws) return false;
   return off <= 160 * 1024;
 }
 
@@ -477,18 +435,12 @@ extern "C" int ubr_conv(const ubr_conv_desc* d, void* stream) {
   k.nunits = d->ntaps * best.UPB; k.steps = best.steps; k.pixb = best.pixb;
   k.rw = (unsigned)(best.HW * best.UPB);
   k.rw_magic = (unsigned)((0x100000000ull + k.rw - 1) / k.rw);
-  k.wl_off = best.wl_off; k.halo_off = best.halo_off; k.red_off = best.red_off; k.xf_off = best.xf_off;
-  k.ntiles = best.tiles_x * best.tiles_y * d->N;
+  k.wl_off = best.wl_off; k.halo_off = best.halo_off; k.red_off = best.red_off;
   k.epilogue = d->epilogue;
   for (int t = 0; t < d->ntaps; ++t) { k.dy[t] = d->dy[t]; k.dx[t] = d->dx[t]; k.wt[t] = d->wt[t]; }
 
   const TileCfg& c = kCfgs[best.cfg];
-  // persistent workgroups: enough to fill the chip several times over, each walking its tiles with a grid stride
-  const int gy = d->Cout_pad / (c.NT * 16);
-  int gx = k.ntiles;
-  const int cap = (512 + gy - 1) / gy;   // two resident workgroups per CU (176-256 VGPRs)
-  if (gx > cap) gx = cap;
-  dim3 grid((unsigned)gx, (unsigned)gy);
+  dim3 grid((unsigned)(best.tiles_x * best.tiles_y * d->N), (unsigned)(d->Cout_pad / (c.NT * 16)));
   hipStream_t st = (hipStream_t)stream;
   switch (d->dtype) {
     case UBR_F32: return launch_T<float>(best.cfg, k, grid, best.lds, st);
