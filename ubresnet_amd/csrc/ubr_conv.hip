@@ -401,6 +401,9 @@ extern "C" int ubr_conv(const ubr_conv_desc* d, void* stream) {
     // widest channel tile that divides Cout_pad; then the largest pixel tile that still yields
     // >= 512 workgroups (2 per CU), else the smallest tile.
     const int order_by_nt[3][4] = {{3, 4, 5, -1}, {2, 6, 8, -1}, {0, 1, 7, 9}};
+    // wide layers (>= 64 output channels) are MFMA/L2-bound: every pixel tile re-stages the weight slab, so prefer
+    // big tiles as long as each CU still gets a workgroup; thin layers are HBM-bound and want >= 2 per CU
+    const long min_wgs = (d->Cout_pad % 64 == 0) ? 256 : 512;
     for (int g = 0; g < 3 && !have; ++g) {
       Plan cand{}; bool any = false;
       for (int i = 0; i < 4; ++i) {
@@ -412,7 +415,7 @@ extern "C" int ubr_conv(const ubr_conv_desc* d, void* stream) {
         if (c.TWF == 2 && d->OW < 32) continue;
         const long wgs = (long)p.tiles_x * p.tiles_y * d->N * (d->Cout_pad / (c.NT * 16));
         cand = p; any = true;
-        if (wgs >= 512 && p.lds <= 80 * 1024) break;
+        if (wgs >= min_wgs && p.lds <= 80 * 1024) break;
       }
       if (any) { best = cand; have = true; }
     }
