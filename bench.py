@@ -28,6 +28,7 @@ import torch.distributed as dist
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
 MODEL_BYTES_PER_IMG_BF16 = 1.50e9   # SURVEY.md section 8d "fused-min v1": train step, bf16
 MODEL_FLOP_PER_IMG = 199.8e9
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # dense peaks, MI355X_MICROARCH.md
 
 
 def parse():
@@ -39,6 +40,8 @@ def parse():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--inplanes", type=int, default=16)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f16"])
+    ap.add_argument("--model", default="uresnet", choices=["uresnet", "aspp"],
+                    help="aspp = BASELINE configs[3]: ASPP_ResNet on 3-plane 512x832 input")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--breakdown-file", default="")
@@ -122,7 +125,13 @@ def main():
 
     dt = {"bf16": torch.bfloat16, "f32": torch.float32, "f16": torch.float16}[a.dtype]
     torch.manual_seed(1234)                     # identical initial weights on every rank (DP replicas)
-    model = UResNet(num_classes=3, input_channels=1, inplanes=a.inplanes).to(dev)
+    if a.model == "aspp":
+        from ubresnet_amd.models.ASPP_ResNet import ASPP_ResNet
+        model = ASPP_ResNet(num_classes=3, in_channels=3, inplanes=16, showsizes=False).to(dev)
+        planes, H, W = 3, 512, 832
+    else:
+        model = UResNet(num_classes=3, input_channels=1, inplanes=a.inplanes).to(dev)
+        planes, H, W = 1, a.size, a.size
     model.compute_dtype = dt
     model.train()
     crit = PixelWiseNLLLoss()
@@ -136,7 +145,7 @@ def main():
     # synthetic crops: rank r holds images [r*b, (r+1)*b) of the global batch, resident in HBM
     gb = a.batch * world
     lo, hi = shard_range(gb, rank, world)
-    x, lab, wgt = synthetic.make_batch(a.batch, a.size, a.size, seed0=1000 + lo)
+    x, lab, wgt = synthetic.make_batch(a.batch, H, W, seed0=1000 + lo * planes, planes=planes)
     x, lab, wgt = torch.from_numpy(x).to(dev), torch.from_numpy(lab).to(dev), torch.from_numpy(wgt).to(dev)
 
     def step():
@@ -172,16 +181,21 @@ def main():
         "value": gb * a.steps / el, "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * el / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": a.dtype, "data": "synthetic",
-        "config": {"workload": "ub_uresnet 3-class ip%d %s, batch %d per GPU (global %d), %dx%dx1 synthetic LArTPC crops, Adam(1e-5, wd 1e-4)"
-                               % (a.inplanes, a.dtype, a.batch, gb, a.size, a.size),
+        "config": {"workload": "%s 3-class ip%d %s, batch %d per GPU (global %d), %dx%dx%d synthetic LArTPC crops, Adam(1e-5, wd 1e-4)"
+                               % ("ub_uresnet" if a.model == "uresnet" else "ASPP_ResNet", a.inplanes, a.dtype, a.batch, gb, H, W, planes),
                    "parallelism": "dp%d" % world, "global_batch": gb},
         "final_loss": lossv,
     }
     esz = 4 if a.dtype == "f32" else 2
-    per_img = MODEL_BYTES_PER_IMG_BF16 * (esz / 2.0) * (a.size * a.size / 262144.0) * (a.inplanes / 16.0)
+    if a.model == "uresnet":
+        per_img = MODEL_BYTES_PER_IMG_BF16 * (esz / 2.0) * (a.size * a.size / 262144.0) * (a.inplanes / 16.0)
+        flop_img = MODEL_FLOP_PER_IMG * (a.size * a.size / 262144.0)
+    else:   # ASPP ip16 @3x512x832: 442.0 M elements train-forward, 169.77 GF forward
+        per_img = 3 * 442.0e6 * esz
+        flop_img = 3 * 169.77e9
     res["step_model"] = {"algorithmic_bytes_per_image": per_img, "achieved_GBs_per_gpu": per_img * a.batch * a.steps / el / 1e9,
                          "frac_of_hbm_peak": per_img * a.batch * a.steps / el / 1e9 / HBM_PEAK_GBS,
-                         "achieved_TFLOPs_per_gpu": MODEL_FLOP_PER_IMG * (a.size * a.size / 262144.0) * a.batch * a.steps / el / 1e12}
+                         "achieved_TFLOPs_per_gpu": flop_img * a.batch * a.steps / el / 1e12}
 
     # ---- per-launch breakdown of one more step (HIP events on the launch stream) -> roofline of the dominant kernel
     if not a.no_breakdown:
@@ -191,21 +205,39 @@ def main():
         ops._prof = None
         torch.cuda.synchronize()
     if rank == 0 and not a.no_breakdown:
-        agg = prof.summary()
-        rows = sorted(((v[1], k, v) for k, v in agg.items()), reverse=True)
-        tot = sum(r[0] for r in rows)
-        (tsum, (name, sig), (cnt, _, nbytes)) = rows[0]
-        ach = nbytes / tsum / 1e9
-        res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                           "traffic": None, "kernel": name, "shape": sig, "launches_per_step": cnt,
-                           "avg_launch_ms": 1e3 * tsum / cnt, "algorithmic_bytes_per_launch": nbytes / cnt,
-                           "share_of_gpu_time": tsum / tot}
+        # dominant KERNEL SYMBOL (as rocprofv3 --kernel-trace --stats names it): launches, average duration and the
+        # algorithmic bytes/flops it moved, all from HIP events recorded on the launch stream in this run
+        bysym = prof.summary(by="kernel")
+        tot = sum(v[1] for v in bysym.values())
+        sym, (cnt, tsum, nbytes, flops) = max(bysym.items(), key=lambda kv: kv[1][1])
+        ai = flops / max(nbytes, 1)
+        peak_tf = MFMA_PEAK_TFLOPS[a.dtype]
+        mfma_bound = ai > peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9)
+        traffic = None
+        try:   # HBM bytes per launch from a committed rocprofv3 --pmc collection of this command (profiles/), if present
+            pm = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
+            if pm.get("dtype") == a.dtype and pm.get("batch") == a.batch and sym in pm.get("kernels", {}):
+                traffic = pm["kernels"][sym]["hbm_bytes_per_launch"]
+        except Exception:
+            pass
+        if mfma_bound:
+            ach = flops / tsum / 1e12
+            res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak_tf, "unit": "TFLOP/s", "frac": ach / peak_tf, "traffic": traffic}
+        else:
+            ach = nbytes / tsum / 1e9
+            res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic}
+        res["roofline"].update({"kernel": sym, "launches_per_step": cnt, "avg_launch_us": 1e6 * tsum / cnt,
+                                "algorithmic_bytes_per_launch": nbytes / cnt, "algorithmic_flop_per_launch": flops / cnt,
+                                "arithmetic_intensity": ai, "share_of_gpu_time": tsum / tot})
         res["kernel_time_ms_per_step"] = 1e3 * tot
         if a.breakdown_file:
             with open(a.breakdown_file, "w") as f:
-                f.write("%-22s %-58s %5s %10s %9s %8s\n" % ("op", "shape", "n", "total_ms", "GB/s", "share"))
-                for tsum_, (nm, sg), (c_, _, nb_) in rows:
-                    f.write("%-22s %-58s %5d %10.3f %9.1f %7.1f%%\n" % (nm, sg, c_, 1e3 * tsum_, nb_ / max(tsum_, 1e-12) / 1e9, 100 * tsum_ / tot))
+                f.write("== by kernel symbol ==\n%-64s %5s %10s %9s %9s %9s %7s\n" % ("kernel", "n", "total_ms", "avg_us", "GB/s", "TFLOP/s", "share"))
+                for sy, (c_, t_, b_, fl_) in sorted(bysym.items(), key=lambda kv: -kv[1][1]):
+                    f.write("%-64s %5d %10.3f %9.1f %9.1f %9.1f %6.1f%%\n" % (sy, c_, 1e3 * t_, 1e6 * t_ / c_, b_ / max(t_, 1e-12) / 1e9, fl_ / max(t_, 1e-12) / 1e12, 100 * t_ / tot))
+                f.write("\n== by (op, shape) ==\n%-14s %-62s %5s %10s %9s %9s %7s\n" % ("op", "shape", "n", "total_ms", "GB/s", "TFLOP/s", "share"))
+                for (nm, sg), (c_, t_, b_, fl_) in sorted(prof.summary(by="shape").items(), key=lambda kv: -kv[1][1]):
+                    f.write("%-14s %-62s %5d %10.3f %9.1f %9.1f %6.1f%%\n" % (nm, sg, c_, 1e3 * t_, b_ / max(t_, 1e-12) / 1e9, fl_ / max(t_, 1e-12) / 1e12, 100 * t_ / tot))
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(a.size, a.inplanes)
     if rank == 0:

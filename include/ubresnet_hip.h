@@ -95,6 +95,9 @@ typedef struct {
 } ubr_conv_desc;
 
 int ubr_conv(const ubr_conv_desc* d, void* stream);
+/* tile configuration (FW, NT, TWF = template arguments of conv_igemm_kernel) chosen by this thread's last
+ * ubr_conv call: lets host-side timing be keyed by kernel symbol, as rocprofv3 reports it */
+void ubr_conv_last_config(int* fw, int* nt, int* twf);
 
 /* Weight repack: fp32 master weights (PyTorch layouts) -> packed image for ubr_conv.
  *   dst[t][ku][m][e] = (T) src[m*sm + (ku*CPU+e)*sk + tapidx[t]],  m < M (zero for M <= m < Mpad)
@@ -128,6 +131,7 @@ typedef struct {
 /* returns the number of slabs the launch will use for this shape (>=1) and the workspace bytes */
 int ubr_wgrad_plan(const ubr_wgrad_desc* d, int32_t* nsplit, int64_t* workspace_bytes);
 int ubr_wgrad(const ubr_wgrad_desc* d, void* stream);
+void ubr_wgrad_last_config(int* ma, int* nb, int* tpg, int* nsplit_mode);   /* template arguments of wgrad_kernel */
 int ubr_wgrad_reduce(float* slabs /* clobbered */, int nsplit, int ntaps, int Cout_pad, int Cin,
                      int Cout_valid, int Cin_valid, float* dst, int64_t sm, int64_t sk,
                      const int32_t* tapidx_host, int accumulate, void* stream);

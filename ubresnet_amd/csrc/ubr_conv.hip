@@ -355,6 +355,13 @@ static bool plan_for(const ubr_conv_desc* d, int cfg, int dymin, int dymax, int 
 
 }  // namespace
 
+static thread_local int g_last_conv_cfg[3] = {0, 0, 0};
+extern "C" void ubr_conv_last_config(int* fw, int* nt, int* twf) {
+  if (fw) *fw = g_last_conv_cfg[0];
+  if (nt) *nt = g_last_conv_cfg[1];
+  if (twf) *twf = g_last_conv_cfg[2];
+}
+
 extern "C" int ubr_conv(const ubr_conv_desc* d, void* stream) {
   UBR_CHECK(d != nullptr, "ubr_conv: null descriptor");
   UBR_CHECK(ubr_dtype_ok(d->dtype), "ubr_conv: bad dtype %d", d->dtype);
@@ -401,9 +408,6 @@ extern "C" int ubr_conv(const ubr_conv_desc* d, void* stream) {
     // widest channel tile that divides Cout_pad; then the largest pixel tile that still yields
     // >= 512 workgroups (2 per CU), else the smallest tile.
     const int order_by_nt[3][4] = {{3, 4, 5, -1}, {2, 6, 8, -1}, {0, 1, 7, 9}};
-    // wide layers (>= 64 output channels) are MFMA/L2-bound: every pixel tile re-stages the weight slab, so prefer
-    // big tiles as long as each CU still gets a workgroup; thin layers are HBM-bound and want >= 2 per CU
-    const long min_wgs = (d->Cout_pad % 64 == 0) ? 256 : 512;
     for (int g = 0; g < 3 && !have; ++g) {
       Plan cand{}; bool any = false;
       for (int i = 0; i < 4; ++i) {
@@ -415,7 +419,7 @@ extern "C" int ubr_conv(const ubr_conv_desc* d, void* stream) {
         if (c.TWF == 2 && d->OW < 32) continue;
         const long wgs = (long)p.tiles_x * p.tiles_y * d->N * (d->Cout_pad / (c.NT * 16));
         cand = p; any = true;
-        if (wgs >= min_wgs && p.lds <= 80 * 1024) break;
+        if (wgs >= 512 && p.lds <= 80 * 1024) break;
       }
       if (any) { best = cand; have = true; }
     }
@@ -443,6 +447,7 @@ extern "C" int ubr_conv(const ubr_conv_desc* d, void* stream) {
   for (int t = 0; t < d->ntaps; ++t) { k.dy[t] = d->dy[t]; k.dx[t] = d->dx[t]; k.wt[t] = d->wt[t]; }
 
   const TileCfg& c = kCfgs[best.cfg];
+  g_last_conv_cfg[0] = c.FW; g_last_conv_cfg[1] = c.NT; g_last_conv_cfg[2] = c.TWF;
   dim3 grid((unsigned)(best.tiles_x * best.tiles_y * d->N), (unsigned)(d->Cout_pad / (c.NT * 16)));
   hipStream_t st = (hipStream_t)stream;
   switch (d->dtype) {

@@ -394,10 +394,19 @@ extern "C" int ubr_wgrad_plan(const ubr_wgrad_desc* d, int32_t* nsplit, int64_t*
   return UBR_OK;
 }
 
+static thread_local int g_last_wgrad_cfg[4] = {0, 0, 0, 0};
+extern "C" void ubr_wgrad_last_config(int* ma, int* nb, int* tpg, int* nsplit_mode) {
+  if (ma) *ma = g_last_wgrad_cfg[0];
+  if (nb) *nb = g_last_wgrad_cfg[1];
+  if (tpg) *tpg = g_last_wgrad_cfg[2];
+  if (nsplit_mode) *nsplit_mode = g_last_wgrad_cfg[3];
+}
+
 extern "C" int ubr_wgrad(const ubr_wgrad_desc* d, void* stream) {
   WPlan p{};
   int rc = wgrad_plan(d, &p);
   if (rc != UBR_OK) return rc;
+  g_last_wgrad_cfg[0] = p.MA; g_last_wgrad_cfg[1] = p.NB; g_last_wgrad_cfg[2] = p.TPG; g_last_wgrad_cfg[3] = p.nsplit_mode;
   const int esz = ubr_esize(d->dtype);
   UBR_CHECK(d->x.p && d->g.p && d->slabs, "ubr_wgrad: null tensor");
   UBR_CHECK(d->nsplit == p.nsplit, "ubr_wgrad: nsplit %d does not match plan %d", d->nsplit, p.nsplit);

@@ -21,21 +21,26 @@ _prof = None
 
 
 class LaunchProfiler:
-    """collects (op, shape signature, algorithmic bytes, start/end events) per C-ABI launch"""
+    """collects (op, kernel symbol, shape signature, algorithmic bytes and flops, start/end events) per launch"""
 
     def __init__(self):
         self.records = []
 
-    def summary(self):
+    def summary(self, by="shape"):
+        """aggregate -> {key: [launches, seconds, bytes, flops]}; by = 'shape' (op, shape) or 'kernel' (symbol)"""
         torch.cuda.synchronize()
         agg = {}
-        for name, sig, nbytes, e0, e1 in self.records:
-            k = (name, sig)
-            a = agg.setdefault(k, [0, 0.0, 0])
+        for name, kern, sig, nbytes, flops, e0, e1 in self.records:
+            k = (name, sig) if by == "shape" else kern
+            a = agg.setdefault(k, [0, 0.0, 0, 0.0])
             a[0] += 1
             a[1] += e0.elapsed_time(e1) * 1e-3
             a[2] += nbytes
+            a[3] += flops
         return agg
+
+
+_DT_NAME = {torch.float32: "float", torch.bfloat16: "bf16_t", torch.float16: "f16_t"}
 
 
 def _act_bytes(args):
@@ -54,15 +59,25 @@ def _timed(name):
             acts = [a for a in list(args) + list(kwargs.values()) if isinstance(a, torch.Tensor) and a.dim() == 4]
             sig = " ".join("x".join(map(str, a.shape)) for a in acts[:3])
             taps = kwargs.get("taps", args[3] if name in ("conv",) and len(args) > 3 else (args[2] if name == "wgrad" and len(args) > 2 else None))
-            if isinstance(taps, (list, tuple)):
-                sig += " taps%d" % len(taps)
+            ntaps = len(taps) if isinstance(taps, (list, tuple)) else 0
+            if ntaps:
+                sig += " taps%d" % ntaps
             if "S" in kwargs:
                 sig += " S%d" % kwargs["S"]
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             r = fn(*args, **kwargs)
             e1.record()
-            _prof.records.append((name, sig, _act_bytes(acts), e0, e1))
+            kern, flops = name, 0.0
+            if name == "conv":
+                x, wp, y = args[0], args[1], args[2]
+                cout = args[4]
+                npix = y.shape[0] * (y.shape[2] * y.shape[3] if y.shape[1] == cout and y.dtype == torch.float32 and kwargs.get("logsoftmax") else y.shape[1] * y.shape[2])
+                flops = 2.0 * npix * x.shape[3] * cout * ntaps
+                a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
+                L.lib().ubr_conv_last_config(C.byref(a), C.byref(b), C.byref(c))
+                kern = "conv_igemm_kernel<%s, %d, %d, %d>" % (_DT_NAME[x.dtype], a.value, b.value, c.value)
+            _prof.records.append((name, kern, sig, _act_bytes(acts), flops, e0, e1))
             return r
         wrapper.__name__ = fn.__name__
         wrapper.__doc__ = fn.__doc__
@@ -214,7 +229,6 @@ class WgradWorkspace:
         return self.buf
 
 
-@_timed("wgrad")
 def wgrad(x: torch.Tensor, g: torch.Tensor, taps, dst: torch.Tensor, sm: int, sk: int, Cout_valid: int, Cin_valid: int,
           ws: WgradWorkspace, S: int = 1, iy0: int = 0, ix0: int = 0, xf: Optional[Affine] = None, accumulate: bool = False,
           dst_offset: int = 0):
@@ -240,11 +254,26 @@ def wgrad(x: torch.Tensor, g: torch.Tensor, taps, dst: torch.Tensor, sm: int, sk
     d.slabs = slabs.data_ptr()
     d.nsplit = nsplit.value
     st = L.stream_ptr()
+    if _prof is not None:
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
     L.check(lib.ubr_wgrad(C.byref(d), st), "wgrad")
+    if _prof is not None:
+        e1.record()
     idx = (C.c_int32 * len(taps))(*[t[2] for t in taps])
     assert dst.dtype == torch.float32
     L.check(lib.ubr_wgrad_reduce(slabs.data_ptr(), nsplit.value, len(taps), d.Cout, Cin, Cout_valid, Cin_valid,
                                  dst.data_ptr() + 4 * dst_offset, sm, sk, idx, 1 if accumulate else 0, st), "wgrad_reduce")
+    if _prof is not None:
+        e2.record()
+        a, b, c, dd = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        lib.ubr_wgrad_last_config(C.byref(a), C.byref(b), C.byref(c), C.byref(dd))
+        kern = "wgrad_kernel<%s, %d, %d, %d, %s>" % (_DT_NAME[x.dtype], a.value, b.value, c.value, "true" if dd.value else "false")
+        sig = "%s %s taps%d S%d" % ("x".join(map(str, x.shape)), "x".join(map(str, g.shape)), len(taps), S)
+        nbytes = (x.numel() + g.numel()) * x.element_size()
+        flops = 2.0 * g.shape[0] * g.shape[1] * g.shape[2] * g.shape[3] * Cin * len(taps)
+        _prof.records.append(("wgrad", kern, sig, nbytes, flops, e0, e1))
+        _prof.records.append(("wgrad_reduce", "wgrad_reduce_kernel (+stage1)", sig, nsplit.value * len(taps) * d.Cout * Cin * 4, 0.0, e1, e2))
 
 
 # ------------------------------------------------------------------------------------------
