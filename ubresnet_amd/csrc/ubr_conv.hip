@@ -161,15 +161,29 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK k) {
         }
       }
     }
-    // ---- stage the weight slab: [unit][TN][16 B], zero beyond nunits ----
-    for (int i = tid; i < 4 * k.steps * TN; i += 256) {
-      const int u = i / TN, nn = i % TN;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (u < k.nunits) {
-        const int tap = u >> k.lgUPB, c = u & (k.UPB - 1);
-        v = ldg16(k.w + ((long)((int)k.wt[tap] * k.CU + blk * k.UPB + c) * k.Cout_pad + n0 + nn) * 16);
+    // ---- stage the weight slab: [unit][TN][16 B], zero beyond nunits; loads batched (WB in flight per thread):
+    // a load -> store per iteration serialises one L2 round trip per item (9 per thread for a 64-channel tile) ----
+    {
+      constexpr int WB = 8;
+      const int nw = 4 * k.steps * TN;
+      for (int ib = tid; ib < nw; ib += 256 * WB) {
+        uint4 v[WB];
+#pragma unroll
+        for (int u = 0; u < WB; ++u) {
+          const int i = ib + u * 256;
+          const int un = i / TN, nn = i % TN;
+          v[u] = make_uint4(0u, 0u, 0u, 0u);
+          if (i < nw && un < k.nunits) {
+            const int tap = un >> k.lgUPB, cc = un & (k.UPB - 1);
+            v[u] = ldg16(k.w + ((long)((int)k.wt[tap] * k.CU + blk * k.UPB + cc) * k.Cout_pad + n0 + nn) * 16);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < WB; ++u) {
+          const int i = ib + u * 256;
+          if (i < nw) *reinterpret_cast<uint4*>(wl + (long)i * 16) = v[u];
+        }
       }
-      *reinterpret_cast<uint4*>(wl + (long)i * 16) = v;
     }
     __syncthreads();
     // ---- MFMA over (tap, cin-unit) ----
