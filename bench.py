@@ -177,7 +177,8 @@ def main():
     lossv = float(loss.item())
 
     res = {
-        "metric": "images/sec, 512x512 U-ResNet train step (fwd+loss+bwd+Adam)",
+        "metric": ("images/sec, 512x512 U-ResNet train step (fwd+loss+bwd+Adam)" if a.model == "uresnet"
+                   else "images/sec, 3x512x832 ASPP-ResNet train step (fwd+loss+bwd+Adam)"),
         "value": gb * a.steps / el, "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * el / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": a.dtype, "data": "synthetic",

@@ -35,6 +35,8 @@ struct ConvK {
   int nunits, steps;
   int pixb;                                      // LDS bytes per halo pixel
   unsigned rw, rw_magic;                         // items per halo row and ceil(2^32/rw)
+  int x_sy32, x_sx32;                            // input row / pixel strides in bytes (per-image offsets fit 31 bits)
+  int step_j, step_hy, step_goff, wrap_goff;     // halo walk: advance of (column item, row, byte offset) per 256 items
   int wl_off, halo_off, red_off;                 // LDS carve offsets
   int epilogue;
   int8_t dy[UBR_MAX_TAPS], dx[UBR_MAX_TAPS];
@@ -99,6 +101,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK k) {
     }
     tbl[u] = off;
   }
+  // per-unit weight-slab source index (in 16-byte items, cin block 0, channel 0): -1 for zero padding units
+  int* wsrc = tbl + 4 * k.steps;
+  for (int u = tid; u < 4 * k.steps; u += 256) {
+    int v = -1;
+    if (u < k.nunits) {
+      const int tap = u >> k.lgUPB, cc = u & (k.UPB - 1);
+      v = ((int)k.wt[tap] * k.CU + cc) * k.Cout_pad;
+    }
+    wsrc[u] = v;
+  }
+  __syncthreads();
 
   f32x4 acc[FW][NT];
 #pragma unroll
@@ -121,8 +134,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK k) {
   for (int blk = 0; blk < k.nblk; ++blk) {
     if (blk) __syncthreads();
     // ---- stage the input halo (transform + zero padding) ----
-    // 256 % UPB == 0, so a thread's channel unit c is fixed: its BatchNorm constants are loaded once per
-    // cin block; global loads are issued in batches of SB before any LDS store.
+    // 256 % UPB == 0, so a thread's channel unit c is fixed (BatchNorm constants loaded once per cin block).
+    // Item i = tid + 256 m maps to halo pixel i >> lgUPB (LDS is linear in i); its (row, column) and global
+    // byte offset advance by constant steps with one conditional wrap -- no division or 64-bit multiply per item.
     {
       constexpr int SB = 4;
       const int c = tid & (k.UPB - 1);
@@ -133,23 +147,25 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK k) {
         for (int e = 0; e < CPU; ++e) { xsub[e] = k.in_sub[ch0 + e]; xsc[e] = k.in_scale[ch0 + e]; xsh[e] = k.in_shift[ch0 + e]; xlo[e] = k.in_lo[ch0 + e]; }
       }
       const char* xc = xn + (long)ch0 * ESZ;
+      int hy = (int)__umulhi((unsigned)tid, k.rw_magic);
+      int j = tid - hy * (int)k.rw;                               // position inside the halo row, in items
+      int goff = (hy0 + hy) * k.x_sy32 + (hx0 + (j >> k.lgUPB)) * k.x_sx32;   // byte offset inside the image
       for (int ib = tid; ib < nitems; ib += 256 * SB) {
         uint4 v[SB];
-        int dst[SB];
         bool ok[SB];
 #pragma unroll
         for (int u = 0; u < SB; ++u) {
-          const int i = ib + u * 256;
-          const int hy = (int)__umulhi((unsigned)i, k.rw_magic);
-          const int hx = (i - hy * (int)k.rw) >> k.lgUPB;
-          const int iy = hy0 + hy, ix = hx0 + hx;
-          dst[u] = (hy * k.HW + hx) * k.pixb + c * 16;
-          ok[u] = i < nitems && (unsigned)iy < (unsigned)k.H && (unsigned)ix < (unsigned)k.W;
+          const int iy = hy0 + hy, ix = hx0 + (j >> k.lgUPB);
+          ok[u] = (ib + u * 256 < nitems) && (unsigned)iy < (unsigned)k.H && (unsigned)ix < (unsigned)k.W;
           v[u] = make_uint4(0u, 0u, 0u, 0u);
-          if (ok[u]) v[u] = ldg16(xc + (long)iy * k.x_sy + (long)ix * k.x_sx);
+          if (ok[u]) v[u] = ldg16(xc + goff);
+          // advance by 256 items
+          j += k.step_j; hy += k.step_hy; goff += k.step_goff;
+          if (j >= (int)k.rw) { j -= (int)k.rw; hy += 1; goff += k.wrap_goff; }
         }
 #pragma unroll
         for (int u = 0; u < SB; ++u) {
+          const int i = ib + u * 256;
           if (has_xf && ok[u]) {
             float f[CPU];
             ET<T>::unpack(v[u], f);
@@ -157,25 +173,26 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK k) {
             for (int e = 0; e < CPU; ++e) f[e] = fmaxf(fmaf(f[e] - xsub[e], xsc[e], xsh[e]), xlo[e]);
             v[u] = ET<T>::pack(f);
           }
-          if (ib + u * 256 < nitems) *reinterpret_cast<uint4*>(halo + dst[u]) = v[u];
+          if (i < nitems) *reinterpret_cast<uint4*>(halo + (i >> k.lgUPB) * k.pixb + c * 16) = v[u];
         }
       }
     }
-    // ---- stage the weight slab: [unit][TN][16 B], zero beyond nunits; loads batched (WB in flight per thread):
-    // a load -> store per iteration serialises one L2 round trip per item (9 per thread for a 64-channel tile) ----
+    // ---- stage the weight slab [unit][TN][16 B] (zero beyond nunits).  A unit's TN items are contiguous in the
+    // packed image, so item i = (unit, nn) needs only a table lookup for the unit's source index; loads are
+    // batched (WB in flight per thread). ----
     {
       constexpr int WB = 8;
       const int nw = 4 * k.steps * TN;
+      const int boff = blk * k.UPB * k.Cout_pad + n0;
       for (int ib = tid; ib < nw; ib += 256 * WB) {
         uint4 v[WB];
 #pragma unroll
         for (int u = 0; u < WB; ++u) {
           const int i = ib + u * 256;
-          const int un = i / TN, nn = i % TN;
           v[u] = make_uint4(0u, 0u, 0u, 0u);
-          if (i < nw && un < k.nunits) {
-            const int tap = un >> k.lgUPB, cc = un & (k.UPB - 1);
-            v[u] = ldg16(k.w + ((long)((int)k.wt[tap] * k.CU + blk * k.UPB + cc) * k.Cout_pad + n0 + nn) * 16);
+          if (i < nw) {
+            const int src = wsrc[i / TN];
+            if (src >= 0) v[u] = ldg16(k.w + ((long)(src + boff + (i % TN))) * 16);
           }
         }
 #pragma unroll
@@ -356,7 +373,7 @@ static bool plan_for(const ubr_conv_desc* d, int cfg, int dymin, int dymax, int 
   const int HH = (TH - 1) * d->S + 1 + (dymax - dymin);
   const int HW = (TW - 1) * d->S + 1 + (dxmax - dxmin);
   const int pixb = UPB * 16 + 16;
-  size_t off = ((size_t)16 * steps + 15) & ~(size_t)15;
+  size_t off = ((size_t)2 * 16 * steps + 15) & ~(size_t)15;   // offset table + weight source table
   p->wl_off = (int)off; off += (size_t)4 * steps * TN * 16;
   p->halo_off = (int)off; off += (size_t)HH * HW * pixb;
   off = (off + 15) & ~(size_t)15;
@@ -456,6 +473,12 @@ extern "C" int ubr_conv(const ubr_conv_desc* d, void* stream) {
   k.nunits = d->ntaps * best.UPB; k.steps = best.steps; k.pixb = best.pixb;
   k.rw = (unsigned)(best.HW * best.UPB);
   k.rw_magic = (unsigned)((0x100000000ull + k.rw - 1) / k.rw);
+  UBR_CHECK((long)d->H * k.x_sy < (1L << 31) && k.x_sx < (1L << 20), "ubr_conv: image too large for 32-bit offsets");
+  k.x_sy32 = (int)k.x_sy; k.x_sx32 = (int)k.x_sx;
+  k.step_j = (int)(256 % k.rw); k.step_hy = (int)(256 / k.rw);
+  // moving step_j items right = (step_j / UPB) pixels (step_j is a multiple of UPB because rw and 256 are)
+  k.step_goff = k.step_hy * k.x_sy32 + (k.step_j >> k.lgUPB) * k.x_sx32;
+  k.wrap_goff = k.x_sy32 - best.HW * k.x_sx32;
   k.wl_off = best.wl_off; k.halo_off = best.halo_off; k.red_off = best.red_off;
   k.epilogue = d->epilogue;
   for (int t = 0; t < d->ntaps; ++t) { k.dy[t] = d->dy[t]; k.dx[t] = d->dx[t]; k.wt[t] = d->wt[t]; }
