@@ -29,6 +29,7 @@ struct WgK {
   int TH, tiles_x, tiles_y, ntiles;
   int pixbG, pixbX, x_off;
   unsigned hw_magic;                             // ceil(2^32 / HW)
+  int x_sy32, x_sx32, g_sy32, g_sx32;            // row / pixel strides in bytes (per-image offsets fit 31 bits)
   int n_cot;
   int8_t dy[UBR_MAX_TAPS], dx[UBR_MAX_TAPS];
 };
@@ -99,31 +100,49 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgK k) {
   uint4 gv[GS], xv[XS];
   unsigned xok = 0u;
 
+  // A thread's staging slots cover the same tile-relative pixels in every tile: their (row, col), bounds keys and
+  // byte offsets relative to the tile origin are computed ONCE, so the per-tile work per 16-byte item is two
+  // bounds compares and one add (no division, no 64-bit multiply).
+  int g_rc[GS], g_rel[GS];                 // (row << 16 | col), byte offset relative to the tile's first pixel
+#pragma unroll
+  for (int u = 0; u < GS; ++u) {
+    const int px = pg0 + u * PGS;
+    g_rc[u] = ((px >> 5) << 16) | (px & 31);
+    g_rel[u] = (px >> 5) * k.g_sy32 + (px & 31) * k.g_sx32;
+  }
+  int x_rc[XS], x_rel[XS];
+#pragma unroll
+  for (int u = 0; u < XS; ++u) {
+    const int px = px0 + u * PXS_T;
+    const int hy = (int)__umulhi((unsigned)px, k.hw_magic), hx = px - hy * k.HW;
+    x_rc[u] = (hy << 16) | hx;
+    x_rel[u] = hy * k.x_sy32 + hx * k.x_sx32;
+  }
+
   auto load_tile = [&](int tile) {
     int tt = tile;
     const int tx = tt % k.tiles_x; tt /= k.tiles_x;
     const int ty = tt % k.tiles_y;
     const int n = tt / k.tiles_y;
     const int oy0 = ty * k.TH, ox0 = tx * 32;
-    const char* gn = k.g + (long)n * k.g_sn + (long)(co0 + cg * CPU) * ESZ;
+    const char* gn = k.g + (long)n * k.g_sn + (long)(co0 + cg * CPU) * ESZ + ((long)oy0 * k.g_sy32 + (long)ox0 * k.g_sx32);
+    const int gry = k.GH - oy0, grx = k.GW - ox0;          // rows / cols of the gradient grid left from the tile origin
 #pragma unroll
     for (int u = 0; u < GS; ++u) {
       const int px = pg0 + u * PGS;
-      const int gy = oy0 + (px >> 5), gx = ox0 + (px & 31);
       gv[u] = make_uint4(0u, 0u, 0u, 0u);
-      if (px < npxG && gy < k.GH && gx < k.GW) gv[u] = ldg16(gn + (long)gy * k.g_sy + (long)gx * k.g_sx);
+      if (px < npxG && (g_rc[u] >> 16) < gry && (g_rc[u] & 0xffff) < grx) gv[u] = ldg16(gn + g_rel[u]);
     }
-    const char* xn = k.x + (long)n * k.x_sn + (long)(ci0 + cx * CPU) * ESZ;
     const int hy0 = oy0 * k.S + k.iy0 + k.dymin, hx0 = ox0 * k.S + k.ix0 + k.dxmin;
+    const char* xn = k.x + (long)n * k.x_sn + (long)(ci0 + cx * CPU) * ESZ + ((long)hy0 * k.x_sy32 + (long)hx0 * k.x_sx32);
     xok = 0u;
 #pragma unroll
     for (int u = 0; u < XS; ++u) {
       const int px = px0 + u * PXS_T;
-      const int hy = (int)__umulhi((unsigned)px, k.hw_magic), hx = px - hy * k.HW;
-      const int iy = hy0 + hy, ix = hx0 + hx;
+      const int iy = hy0 + (x_rc[u] >> 16), ix = hx0 + (x_rc[u] & 0xffff);
       const bool ok = px < npxX && (unsigned)iy < (unsigned)k.H && (unsigned)ix < (unsigned)k.W;
       xv[u] = make_uint4(0u, 0u, 0u, 0u);
-      if (ok) { xv[u] = ldg16(xn + (long)iy * k.x_sy + (long)ix * k.x_sx); xok |= 1u << u; }
+      if (ok) { xv[u] = ldg16(xn + x_rel[u]); xok |= 1u << u; }
     }
   };
   auto store_tile = [&]() {
@@ -429,6 +448,8 @@ extern "C" int ubr_wgrad(const ubr_wgrad_desc* d, void* stream) {
   k.TH = p.TH; k.tiles_x = p.tiles_x; k.tiles_y = p.tiles_y; k.ntiles = p.ntiles;
   k.pixbG = p.pixbG; k.pixbX = p.pixbX; k.x_off = p.x_off;
   k.hw_magic = (unsigned)((0x100000000ull + (unsigned)p.HW - 1) / (unsigned)p.HW);
+  UBR_CHECK((long)d->H * k.x_sy < (1L << 31) && (long)d->GH * k.g_sy < (1L << 31), "ubr_wgrad: image too large for 32-bit offsets");
+  k.x_sy32 = (int)k.x_sy; k.x_sx32 = (int)k.x_sx; k.g_sy32 = (int)k.g_sy; k.g_sx32 = (int)k.g_sx;
   k.n_cot = d->Cout / (p.MA * 16);
   for (int t = 0; t < d->ntaps; ++t) { k.dy[t] = d->dy[t]; k.dx[t] = d->dx[t]; }
   hipStream_t st = (hipStream_t)stream;
