@@ -107,6 +107,17 @@ void ubr_conv_last_config(int* fw, int* nt, int* twf);
 int ubr_pack_weights(int dtype, const float* src, void* dst, int M, int Mpad, int Kvalid, int Kpad,
                      int64_t sm, int64_t sk, int ntaps, const int32_t* tapidx_host, void* stream);
 
+/* All weight images of a network in ONE launch (a train step repacks ~115 tensors; the fused optimizers do
+ * not bump tensor version counters, so the executor repacks every pass instead of caching).  `items_dev` is
+ * a DEVICE array; each item is one ubr_pack_weights call with tapidx[t] = t * tap_stride, KU = Kpad / CPU. */
+typedef struct {
+  const float* src;
+  void* dst;
+  int64_t sm, sk, tap_stride;
+  int32_t M, Mpad, Kvalid, KU, ntaps, pad_;
+} ubr_pack_item;
+int ubr_pack_weights_batched(int dtype, const ubr_pack_item* items_dev, int nitems, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Weight gradient (autograd ConvolutionBackward, weight part) on MFMA with pixels as K.
  *   dW[t][co][ci] = sum_{n,oy,ox} g(n,oy,ox,co) * xform(x)(n, oy*S+iy0+dy[t], ox*S+ix0+dx[t], ci)

@@ -45,6 +45,8 @@ def _run(eng, fwd, bwd, go):
     sv = Saved()
     eng._alloc_pass_workspaces(sv, torch.device(DEV), True)
     eng._save = True
+    eng.pack_all(torch.float32, torch.device(DEV, 0), "fwd")
+    eng.pack_all(torch.float32, torch.device(DEV, 0), "bwd")
     rec = fwd()
     flat = torch.zeros(eng.grad_numel, device=DEV)
     views = {}
@@ -179,6 +181,7 @@ def test_stem_on_matrix_cores(cfg, dt):
     ref = F.conv2d(xq, wr, br, 1, 3)
     c0 = torch.empty((N, H, W, Cout), dtype=dt, device=DEV)
     stats = torch.zeros(32 * 2 * Cout, dtype=torch.float64, device=DEV)
+    eng.pack_all(dt, torch.device(DEV, 0), "fwd")
     x16 = eng.stem_fwd(st.conv1, x.to(DEV), c0, stats, dt)
     torch.cuda.synchronize()
     tol = 2e-5 if dt == torch.float32 else 1.2e-2

@@ -272,3 +272,31 @@ def test_errors_are_exceptions():
         m(torch.zeros(1, 3, 64, 64, device="cuda"))       # wrong channel count
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 1, 64, 64))                      # CPU tensor: no fallback
+
+
+def test_weights_updated_by_fused_optimizer_are_used():
+    """torch's fused Adam updates parameters WITHOUT bumping their version counters; the executor must not
+    serve stale packed weight images (regression test: it repacks every pass)."""
+    sd = O.seeded_state_dict(O.uresnet_schema(3, 1, 16, 16), 42)
+    x, lab, wgt = synthetic.make_batch(1, 64, 64, 1000)
+    xd, ld, wd = torch.from_numpy(x).cuda(), torch.from_numpy(lab).cuda(), torch.from_numpy(wgt).cuda()
+    m = _model(sd)
+    m.train()
+    try:
+        opt = torch.optim.Adam(m.parameters(), lr=1e-2, fused=True)
+    except Exception:
+        pytest.skip("fused Adam unavailable")
+    crit = PixelWiseNLLLoss()
+    loss = crit(m(xd), ld, wd)
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    m.eval()
+    with torch.no_grad():
+        after = m(xd)
+    fresh = _model({k: v.detach().cpu() for k, v in m.state_dict().items()})
+    fresh.eval()
+    with torch.no_grad():
+        want = fresh(xd)
+    assert torch.equal(after, want), "forward after a fused optimizer step used stale weights"
+    assert (after - want).abs().max().item() == 0.0

@@ -524,6 +524,40 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackK k) {
 }
 }  // namespace
 
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void pack_batched_kernel(const ubr_pack_item* items) {
+  constexpr int CPU = ET<T>::CPU;
+  const ubr_pack_item it = items[blockIdx.y];
+  const long total = (long)it.ntaps * it.KU * it.Mpad;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int m = (int)(i % it.Mpad);
+    long r = i / it.Mpad;
+    const int ku = (int)(r % it.KU);
+    const int t = (int)(r / it.KU);
+    float f[CPU];
+#pragma unroll
+    for (int e = 0; e < CPU; ++e) {
+      const int kc = ku * CPU + e;
+      f[e] = (m < it.M && kc < it.Kvalid) ? it.src[(long)m * it.sm + (long)kc * it.sk + (long)t * it.tap_stride] : 0.f;
+    }
+    *reinterpret_cast<uint4*>((char*)it.dst + i * 16) = ET<T>::pack(f);
+  }
+}
+}  // namespace
+
+extern "C" int ubr_pack_weights_batched(int dtype, const ubr_pack_item* items_dev, int nitems, void* stream) {
+  UBR_CHECK(ubr_dtype_ok(dtype), "ubr_pack_weights_batched: bad dtype");
+  UBR_CHECK(items_dev != nullptr && nitems >= 1 && nitems <= 65535, "ubr_pack_weights_batched: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(48, (unsigned)nitems);
+  if (dtype == UBR_F32) hipLaunchKernelGGL(pack_batched_kernel<float>, grid, dim3(256), 0, st, items_dev);
+  else if (dtype == UBR_BF16) hipLaunchKernelGGL(pack_batched_kernel<bf16_t>, grid, dim3(256), 0, st, items_dev);
+  else hipLaunchKernelGGL(pack_batched_kernel<f16_t>, grid, dim3(256), 0, st, items_dev);
+  UBR_LAUNCH_CHECK("ubr_pack_weights_batched");
+  return UBR_OK;
+}
+
 extern "C" int ubr_pack_weights(int dtype, const float* src, void* dst, int M, int Mpad, int Kvalid, int Kpad,
                                 int64_t sm, int64_t sk, int ntaps, const int32_t* tapidx_host, void* stream) {
   UBR_CHECK(ubr_dtype_ok(dtype), "ubr_pack_weights: bad dtype");

@@ -536,7 +536,7 @@ static int tail_bwd_common(bool apply, int dtype, int64_t npix, int C, const voi
   k.s2 = scale2; k.t2 = shift2; k.m2 = mean2; k.i2 = invstd2; k.k1_2 = k1_2; k.k2_2 = k2_2;
   k.sb = scale_b; k.mb = mean_b; k.ib = invstd_b; k.k1_b = k1_b; k.k2_b = k2_b;
   k.red2 = red2; k.redb = red_b; k.g_c2 = g_c2; k.g_sc = g_sc; k.g_c2_ps = g_c2_ps; k.g_sc_ps = g_sc_ps;
-  const int blocks = pick_blocks(npix, k.CU, apply ? 2048 : 1024);
+  const int blocks = pick_blocks(npix, k.CU, apply ? 2048 : 512);
   const size_t lds = apply ? 0 : (size_t)4 * C * sizeof(double);
   if (apply) { UBR_DT_SWITCH(dtype, hipLaunchKernelGGL((tail_bwd_kernel<TT, true>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, k)); }
   else { UBR_DT_SWITCH(dtype, hipLaunchKernelGGL((tail_bwd_kernel<TT, false>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, k)); }

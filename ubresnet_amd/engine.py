@@ -53,7 +53,8 @@ class Engine:
     def __init__(self, model, kind: str):
         self.model = model
         self.kind = kind  # "uresnet" | "aspp"
-        self._pack_cache: Dict[tuple, tuple] = {}
+        self._plans: Dict[tuple, dict] = {}
+        self._images: Dict[tuple, torch.Tensor] = {}
         self._const: Dict[tuple, torch.Tensor] = {}
         self.wws = ops.WgradWorkspace()
         self.bn_sites: List[BNSite] = []
@@ -87,30 +88,83 @@ class Engine:
     def relu_affine(self, site: BNSite) -> Affine:
         return Affine(site.mean, site.scale, site.shift, self.const(site.scale.device, 0.0, site.C))
 
+    # ------------------------------------------------------------------ weight images
+    # Every pass repacks ALL weight images with one batched launch per direction (forward images at the start
+    # of forward, data-gradient images at the start of backward).  Nothing is cached across passes: fused
+    # optimizers (torch._fused_adam_) update parameters without bumping their version counters, so a cache keyed
+    # on `_version` silently trains on stale weights.
+    def _plan_items(self):
+        """[(group, key, param, src_offset, M, Kvalid, Kpad_or_None, sm, sk, ntaps, tap_stride)]"""
+        m = self.model
+        items = []
+        conv1 = getattr(m, "conv1", None)
+        conv11 = getattr(m, "conv11", None)
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.ConvTranspose2d):
+                w = mod.weight
+                d0, d1, kh, kw = w.shape
+                kk = kh * kw
+                items.append(("fwd", (id(w), "tfwd"), w, 0, d1, d0, None, kk, d1 * kk, kk, 1))
+                items.append(("bwd", (id(w), "tdgrad"), w, 0, d0, d1, None, d1 * kk, kk, kk, 1))
+            elif isinstance(mod, torch.nn.Conv2d):
+                w = mod.weight
+                d0, d1, kh, kw = w.shape
+                kk = kh * kw
+                if mod is conv1 and self.kind != "custom":
+                    for ci in range(d1):     # stem: packed[ky][kx (7 of 16)][co] = w[co][ci][ky][kx]
+                        items.append(("fwd", (id(w), "stem%d" % ci), w, ci * 49, d0, 7, 16, d1 * 49, 1, 7, 7))
+                    continue
+                items.append(("fwd", (id(w), "fwd"), w, 0, d0, d1, None, d1 * kk, kk, kk, 1))
+                if mod is conv11 and self.kind != "custom":   # K (= num_classes) zero-padded to the 16 channels of g_logits
+                    items.append(("bwd", (id(w), "dgrad"), w, 0, d1, d0, 16, kk, d1 * kk, kk, 1))
+                else:
+                    items.append(("bwd", (id(w), "dgrad"), w, 0, d1, d0, None, kk, d1 * kk, kk, 1))
+        if self.kind == "custom":             # test harnesses wrap single blocks: a 7x7 stem conv gets stem images too
+            for mod in m.modules():
+                if isinstance(mod, torch.nn.Conv2d) and mod.kernel_size == (7, 7) and mod.in_channels <= 4:
+                    w = mod.weight
+                    for ci in range(w.shape[1]):
+                        items.append(("fwd", (id(w), "stem%d" % ci), w, ci * 49, w.shape[0], 7, 16, w.shape[1] * 49, 1, 7, 7))
+        return items
+
+    def _pack_plan(self, dt, device):
+        import struct
+        key = (dt, device)
+        plan = self._plans.get(key)
+        ptrs = tuple(p.data_ptr() for _, p in self.grad_order)
+        if plan is not None and plan["ptrs"] == ptrs:
+            return plan
+        cpu = L.chans_per_unit(dt)
+        images, tables = {}, {"fwd": b"", "bwd": b""}
+        counts = {"fwd": 0, "bwd": 0}
+        for group, k, w, soff, M, Kv, Kpad, sm, sk, ntaps, tstride in self._plan_items():
+            if not w.is_contiguous() or w.dtype != torch.float32 or w.device != device:
+                raise RuntimeError("ubresnet_amd: parameters must be contiguous float32 on %s" % device)
+            Mpad = (M + 15) // 16 * 16
+            Kp = Kpad if Kpad is not None else (Kv + cpu - 1) // cpu * cpu
+            dst = torch.empty((ntaps, Kp // cpu, Mpad, cpu), dtype=dt, device=device)
+            images[k] = dst
+            tables[group] += struct.pack("<QQqqqiiiiii", w.data_ptr() + 4 * soff, dst.data_ptr(), sm, sk, tstride, M, Mpad, Kv, Kp // cpu, ntaps, 0)
+            counts[group] += 1
+        plan = {"ptrs": ptrs, "images": images, "counts": counts}
+        for g in ("fwd", "bwd"):
+            plan[g] = torch.frombuffer(bytearray(tables[g]), dtype=torch.uint8).to(device) if counts[g] else None
+        self._plans[key] = plan
+        return plan
+
+    def pack_all(self, dt, device, group):
+        plan = self._pack_plan(dt, device)
+        if plan["counts"][group]:
+            L.check(L.lib().ubr_pack_weights_batched(L.dtype_id(dt), plan[group].data_ptr(), plan["counts"][group], L.stream_ptr()),
+                    "pack_weights_batched")
+        self._images = plan["images"]
+
     def packed(self, param: torch.Tensor, dtype, orient: str) -> torch.Tensor:
-        """cached packed image of a weight (repacked when the parameter changes)"""
-        key = (id(param), orient, dtype)
-        ver = (param._version, param.data_ptr())
-        hit = self._pack_cache.get(key)
-        if hit is not None and hit[0] == ver:
-            return hit[1]
-        w = param.detach()
-        if not w.is_contiguous():
-            w = w.contiguous()
-        d0, d1, kh, kw = w.shape
-        kk = kh * kw
-        if orient == "fwd":        # Conv2d [Cout][Cin][k][k]: M=Cout, K=Cin
-            pk = ops.pack_weights(w, dtype, d0, d1, d1 * kk, kk, kk)
-        elif orient == "dgrad":    # M=Cin, K=Cout
-            pk = ops.pack_weights(w, dtype, d1, d0, kk, d1 * kk, kk)
-        elif orient == "tfwd":     # ConvTranspose2d [Cin][Cout][k][k] forward: M=Cout, K=Cin
-            pk = ops.pack_weights(w, dtype, d1, d0, kk, d1 * kk, kk)
-        elif orient == "tdgrad":   # ConvTranspose2d data gradient: M=Cin, K=Cout
-            pk = ops.pack_weights(w, dtype, d0, d1, d1 * kk, kk, kk)
-        else:
-            raise ValueError(orient)
-        self._pack_cache[key] = (ver, pk)
-        return pk
+        """packed image of a weight for this pass (written by pack_all)"""
+        return self._images[(id(param), orient)]
+
+    def _packed_dgrad_padded(self, w_param, dt):
+        return self._images[(id(w_param), "dgrad")]
 
     def _alloc_pass_workspaces(self, sv: Saved, device, training: bool):
         nf = sum(4 * s.C for s in self.bn_sites)
@@ -326,18 +380,9 @@ class Engine:
         ops.stem_expand(x, x16)
         w = conv1.weight
         for ci in range(Cin):
-            key = (id(w), "stem%d" % ci, dt)
-            ver = (w._version, w.data_ptr())
-            hit = self._pack_cache.get(key)
-            if hit is None or hit[0] != ver:
-                # packed[ky][kx (7 of 16)][co] = w[co][ci][ky][kx]
-                pk = ops.pack_weights(w.detach(), dt, Cout, 7, Cin * 49, 1, 7, tapidx=[7 * ky for ky in range(7)],
-                                      Kpad=16, src_offset=ci * 49)
-                hit = (ver, pk)
-                self._pack_cache[key] = hit
             last = ci == Cin - 1
-            ops.conv(x16[..., 16 * ci:16 * ci + 16], hit[1], c0, self.STEM_TAPS, Cout, bias=conv1.bias if ci == 0 else None,
-                     addend=c0 if ci > 0 else None, stats=stats if last else None)
+            ops.conv(x16[..., 16 * ci:16 * ci + 16], self.packed(w, dt, "stem%d" % ci), c0, self.STEM_TAPS, Cout,
+                     bias=conv1.bias if ci == 0 else None, addend=c0 if ci > 0 else None, stats=stats if last else None)
         return x16
 
     def stem_bwd(self, conv1, x16, g_c0, G):
@@ -517,6 +562,7 @@ class Engine:
         dev, ip = x.device, m.inplanes
         sv = Saved()
         self._alloc_pass_workspaces(sv, dev, training)
+        self.pack_all(dt, dev, "fwd")
         E = lambda *shape: torch.empty(shape, dtype=dt, device=dev)
         C3, C4, C5 = 8 * ip, 16 * ip, 32 * ip
         # affine arena: [acat3 | acat4 | acat5 | cat4 (up,post3,e3) | cat5 (up,post4,e4) | skip5 (post5,e5)]
@@ -583,6 +629,7 @@ class Engine:
         m = self.model
         dt, dev = sv.dt, sv.x.device
         self._rebind(sv)
+        self.pack_all(dt, dev, "bwd")
         flat, views = self._grad_views(dev)
         G = lambda p: views[id(p)]
         stage_done = self._stage_notifier(flat, grad_ready)
@@ -639,6 +686,7 @@ class Engine:
         ip = m.inplanes
         sv = Saved()
         self._alloc_pass_workspaces(sv, dev, training)
+        self.pack_all(dt, dev, "fwd")
         E = lambda *shape: torch.empty(shape, dtype=dt, device=dev)
 
         # stem: conv1 -> (bn1 + relu folded into consumers) -> pool ; x0 goes into dec1's concat buffer
@@ -699,6 +747,7 @@ class Engine:
         dt = sv.dt
         dev = sv.x.device
         self._rebind(sv)
+        self.pack_all(dt, dev, "bwd")
         flat = torch.empty(self.grad_numel, dtype=torch.float32, device=dev)
         views = {}
         for name, p in self.grad_order:
@@ -767,26 +816,6 @@ class Engine:
         self.stem_bwd(m.conv1, sv.x16, g_c0, G)
         stage_done(self.grad_order[-1][1])
         return flat, views
-
-    def _packed_dgrad_padded(self, w_param, dt):
-        """dgrad image of conv11: K (= num_classes) zero-padded to the 16 channels of g_logits"""
-        key = (id(w_param), "dgrad16", dt)
-        ver = (w_param._version, w_param.data_ptr())
-        hit = self._pack_cache.get(key)
-        if hit is not None and hit[0] == ver:
-            return hit[1]
-        w = w_param.detach()
-        Cout, Cin, kh, kw = w.shape
-        kk = kh * kw
-        cpu = L.chans_per_unit(dt)
-        import ctypes as C
-        Mpad = (Cin + 15) // 16 * 16
-        dst = torch.empty((kk, 16 // cpu, Mpad, cpu), dtype=dt, device=w.device)
-        idx = (C.c_int32 * kk)(*range(kk))
-        L.check(L.lib().ubr_pack_weights(L.dtype_id(dt), w.data_ptr(), dst.data_ptr(), Cin, Mpad, Cout, 16, kk, Cin * kk, kk, idx,
-                                         L.stream_ptr()), "pack(conv11 dgrad)")
-        self._pack_cache[key] = (ver, dst)
-        return dst
 
     # ------------------------------------------------------------------ dispatch
     def forward(self, x, training, dt, save):
