@@ -300,3 +300,33 @@ def test_weights_updated_by_fused_optimizer_are_used():
         want = fresh(xd)
     assert torch.equal(after, want), "forward after a fused optimizer step used stale weights"
     assert (after - want).abs().max().item() == 0.0
+
+
+def test_inplanes32_variant():
+    """UResNet(inplanes=32) -- the value training/train_ubresnet2018_wlarcv2.py:88 passes -- against the oracle."""
+    sd = O.seeded_state_dict(O.uresnet_schema(3, 1, 32, 16), 11)
+    x, lab, wgt = synthetic.make_batch(1, 64, 64, 1500)
+    xt = torch.from_numpy(x)
+    m = UResNet(num_classes=3, input_channels=1, inplanes=32)
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    out = m(xt.cuda())
+    loss = PixelWiseNLLLoss()(out, torch.from_numpy(lab).cuda(), torch.from_numpy(wgt).cuda())
+    loss.backward()
+    ref = O.uresnet_forward(sd, xt, True, None)
+    assert _rel(out.detach().cpu(), ref) <= 1e-3
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters())
+    assert sum(p.numel() for p in m.parameters()) == 72340003          # SURVEY.md section 8a row a5
+
+
+def test_device_stager_feeds_training():
+    from ubresnet_amd.synthetic import SyntheticLArCVDataset, DeviceStager
+    ld = SyntheticLArCVDataset(height=64, width=64, tag="train", nentries=8)
+    ld.start(2)
+    st = DeviceStager(ld, 2, 64, 64, tag="train")
+    a1, l1, w1 = st.next()
+    a2, l2, w2 = st.next()
+    want, wl, ww = synthetic.make_batch(4, 64, 64, 1000)
+    assert a1.is_cuda and l1.dtype == torch.int64 and tuple(a1.shape) == (2, 1, 64, 64)
+    assert torch.equal(a1.cpu(), torch.from_numpy(want[:2])) and torch.equal(a2.cpu(), torch.from_numpy(want[2:4]))
+    assert torch.equal(l2.cpu(), torch.from_numpy(wl[2:4])) and torch.equal(w1.cpu(), torch.from_numpy(ww[:2]))

@@ -137,3 +137,56 @@ class SyntheticLArCVDataset(object):
         return {"source_%s" % self.tag: adc.reshape(-1),
                 "label_%s" % self.tag: lab.reshape(-1),
                 "weight_%s" % self.tag: wgt.reshape(-1)}
+
+
+class DeviceStager(object):
+    """Double-buffered host->device staging of loader batches.
+
+    Wraps any object with the larcvdataset interface (``loader[0] -> {name: flat float32 ndarray}``): while the
+    training loop consumes batch i on the compute stream, batch i+1 is copied from pinned host memory on a side
+    stream.  ``next()`` returns ``(adc [B,planes,H,W] float32, label [B,H,W] int64, weight [B,H,W] float32)``
+    device tensors, i.e. what ``prep_data`` (training/train_ubresnet2018_wlarcv2.py:576-615) builds, already on
+    the GPU (the reference discards its ``.to(device)`` results, :611-613).
+    """
+
+    def __init__(self, loader, batchsize, height, width, planes=1, tag="train", device="cuda"):
+        import torch
+        self.torch = torch
+        self.loader, self.tag = loader, tag
+        self.shape = (int(batchsize), int(planes), int(height), int(width))
+        self.device = torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        b, p, h, w = self.shape
+        self._pin = [(torch.empty((b, p, h, w), dtype=torch.float32).pin_memory(),
+                      torch.empty((b, h, w), dtype=torch.int64).pin_memory(),
+                      torch.empty((b, h, w), dtype=torch.float32).pin_memory()) for _ in range(2)]
+        self._slot = 0
+        self._inflight = None
+        self._prefetch()
+
+    def _prefetch(self):
+        torch = self.torch
+        b, p, h, w = self.shape
+        data = self.loader[0]
+        src, lab, wgt = self._pin[self._slot]
+        src.copy_(torch.from_numpy(data["source_%s" % self.tag].reshape((b, p, h, w))))
+        lab.copy_(torch.from_numpy(data["label_%s" % self.tag].reshape((b, h, w))))        # float32 -> int64
+        key = "weight_%s" % self.tag
+        if key in data:
+            wgt.copy_(torch.from_numpy(data[key].reshape((b, h, w))))
+        else:
+            wgt.fill_(1.0)
+        with torch.cuda.stream(self.stream):
+            dev = tuple(t.to(self.device, non_blocking=True) for t in (src, lab, wgt))
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self._inflight = (dev, ev)
+        self._slot ^= 1
+
+    def next(self):
+        dev, ev = self._inflight
+        self.torch.cuda.current_stream(self.device).wait_event(ev)
+        for t in dev:
+            t.record_stream(self.torch.cuda.current_stream(self.device))
+        self._prefetch()
+        return dev
