@@ -110,7 +110,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ
+    if world > 1 or launched:
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     elif a.gpus != 1:
@@ -140,7 +141,7 @@ def main():
         opt = torch.optim.Adam(params, lr=1e-5, weight_decay=1e-4, fused=True)   # reference: Adam(lr 1e-5, wd 1e-4), wlarcv2.py:155-157
     except Exception:
         opt = torch.optim.Adam(params, lr=1e-5, weight_decay=1e-4)
-    reducer = GradAllReducer(model) if world > 1 else None
+    reducer = GradAllReducer(model) if dist.is_initialized() else None
 
     # synthetic crops: rank r holds images [r*b, (r+1)*b) of the global batch, resident in HBM
     gb = a.batch * world
@@ -160,17 +161,17 @@ def main():
 
     for _ in range(a.warmup):
         step()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     el = time.perf_counter() - t0
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
@@ -243,7 +244,7 @@ def main():
         res["cpu_baseline"] = cpu_baseline(a.size, a.inplanes)
     if rank == 0:
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

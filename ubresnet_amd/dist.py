@@ -20,6 +20,9 @@ class GradAllReducer:
         self.model = model
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        import os
+        # UBR_FORCE_REDUCER=1 exercises the bucketed async all-reduce even with one rank (single-GPU rehearsal)
+        self.force = os.environ.get("UBR_FORCE_REDUCER", "0") == "1" and dist.is_initialized()
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.stream = None
         self.pending_lo = None
@@ -31,7 +34,7 @@ class GradAllReducer:
 
     # called by the executor on the compute stream: flat[lo:hi] is final
     def _hook(self, flat: torch.Tensor, lo: int, hi: int):
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         if self.flat is not flat:
             self.flat, self.pending_lo, self.pending_hi = flat, lo, lo
@@ -59,7 +62,7 @@ class GradAllReducer:
 
     def finish(self):
         """make the compute stream wait for every outstanding bucket (call before optimizer.step)"""
-        if self.world == 1 or self.flat is None:
+        if (self.world == 1 and not self.force) or self.flat is None:
             return
         if self.pending_hi is not None and self.pending_hi > self.pending_lo:
             self._launch(self.pending_lo, self.pending_hi)
