@@ -43,7 +43,9 @@ elif what.startswith("wgrad"):
     x, g = mk(N, HW, HW, Cin), mk(N, HW, HW, Cout)
     dW = torch.empty(Cout, Cin, k, k, device=dev)
     ws = ops.WgradWorkspace()
-    fn = lambda: ops.wgrad(x, g, ops.conv_taps(k, 1, k // 2), dW, Cin * k * k, k * k, Cout, Cin, ws, xf=aff(Cin))
+    xfw = aff(Cin)
+    taps = ops.conv_taps(k, 1, k // 2)
+    fn = lambda: ops.wgrad(x, g, taps, dW, Cin * k * k, k * k, Cout, Cin, ws, xf=xfw)
     nbytes = x.numel() * 2 + g.numel() * 2
     flops = 2.0 * N * HW * HW * Cin * Cout * k * k
 else:

@@ -69,7 +69,7 @@ template <> __device__ __forceinline__ void load4<f16_t>(const char* p, float* v
 }
 
 template <typename T, int FW, int NT, int TWF>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK k) {
+__global__ __launch_bounds__(256, ((NT == 4 && FW <= 2) ? 4 : 2)) void conv_igemm_kernel(const ConvK k) {
   constexpr int TN = NT * 16;
   constexpr int F = 4 * FW;
   constexpr int TH = F / TWF;

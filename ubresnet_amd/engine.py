@@ -57,6 +57,9 @@ class Engine:
         self._images: Dict[tuple, torch.Tensor] = {}
         self._const: Dict[tuple, torch.Tensor] = {}
         self.wws = ops.WgradWorkspace()
+        self.side = None
+        self.join = None
+        self._side_on = False
         self.bn_sites: List[BNSite] = []
         self._bn_of: Dict[int, BNSite] = {}
         for m in model.modules():
@@ -238,6 +241,33 @@ class Engine:
         rec.blk, rec.x, rec.c1, rec.c2, rec.cb, rec.out, rec.xf_in = blk, x, c1, c2, cb, out, xf_in
         return rec
 
+    # ------------------------------------------------------------------ weight-gradient side stream
+    def _side_begin(self, dev):
+        """Weight gradients depend on nothing downstream, so they run on a second HIP stream next to the
+        dgrad / BatchNorm-backward chain: the low-resolution layers launch too few workgroups to fill 256 CUs
+        on their own.  Disabled while the launch profiler is attached (per-kernel times must not overlap)."""
+        import os
+        self._side_on = dev.type == "cuda" and ops._prof is None and os.environ.get("UBR_WGRAD_STREAM", "1") != "0"
+        if self._side_on and self.side is None:
+            self.side = torch.cuda.Stream(device=dev)
+            self.join = torch.cuda.Stream(device=dev)
+
+    def _side_end(self, dev):
+        if self._side_on:
+            torch.cuda.current_stream(dev).wait_stream(self.side)
+            self._side_on = False
+
+    def _wg(self, x, g, *args, **kw):
+        if not self._side_on:
+            return ops.wgrad(x, g, *args, **kw)
+        main = torch.cuda.current_stream(x.device)
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
+            ops.wgrad(x, g, *args, **kw)
+        # the caching allocator must not hand these blocks to later main-stream kernels while the side stream reads them
+        x.record_stream(self.side)
+        g.record_stream(self.side)
+
     def _bn_bwd(self, site: BNSite, ga, ga2, c, relu, G, cnt):
         """backward through a = relu(bn(c)) (or bn only): returns g_c; writes dgamma/dbeta"""
         red = ops.stat_buffer(2 * site.C, c.device)
@@ -295,16 +325,16 @@ class Engine:
                                  k[2 * Cout:3 * Cout] if byp else None, k[3 * Cout:] if byp else None, g_c2, g_sc)
         # conv2: weight grad (input = relu(bn1(c1)) re-formed on load) and data grad
         kk = 9
-        ops.wgrad(c1, g_c2, T3, G(blk.conv2.weight), Cout * kk, kk, Cout, Cout, self.wws, xf=self.relu_affine(bn1))
+        self._wg(c1, g_c2, T3, G(blk.conv2.weight), Cout * kk, kk, Cout, Cout, self.wws, xf=self.relu_affine(bn1))
         g_a1 = torch.empty(c1.shape, dtype=dt, device=dev)
         self._conv_dgrad(blk.conv2, g_c2, g_a1, 1)
         del g_c2
         g_c1 = self._bn_bwd(bn1, g_a1, None, c1, True, G, cnt)
         del g_a1
         Cin = x.shape[3]
-        ops.wgrad(x, g_c1, T3, G(blk.conv1.weight), Cin * kk, kk, Cout, Cin, self.wws, S=S, xf=rec.xf_in)
+        self._wg(x, g_c1, T3, G(blk.conv1.weight), Cin * kk, kk, Cout, Cin, self.wws, S=S, xf=rec.xf_in)
         if byp:
-            ops.wgrad(x, g_sc, T1, G(blk.bypass.weight), Cin, 1, Cout, Cin, self.wws, S=S, xf=rec.xf_in)
+            self._wg(x, g_sc, T1, G(blk.bypass.weight), Cin, 1, Cout, Cin, self.wws, S=S, xf=rec.xf_in)
         if not need_gx:
             return None
         gx = torch.empty(x.shape, dtype=dt, device=dev)
@@ -361,7 +391,7 @@ class Engine:
         for ry in range(2):
             for rx in range(2):
                 taps = ops.transposed_phase_taps(4, 1, 1, 2, ry, rx)
-                ops.wgrad(x, _phase(g_up, ry, rx), taps, dW, 16, Cd * 16, Cd, Cin, self.wws, xf=xf_x)
+                self._wg(x, _phase(g_up, ry, rx), taps, dW, 16, Cd * 16, Cd, Cin, self.wws, xf=xf_x)
         # data gradient of the transposed conv = ordinary stride-2 conv over g_up
         gx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
         wp = self.packed(dl.deconv.weight, x.dtype, "tdgrad")
@@ -391,7 +421,7 @@ class Engine:
         dW = G(conv1.weight)
         taps = [(ky - 3, 0, 7 * ky) for ky in range(7)]
         for ci in range(Cin):
-            ops.wgrad(x16[..., 16 * ci:16 * ci + 16], g_c0, taps, dW, Cin * 49, 1, Cout, 7, self.wws, dst_offset=ci * 49)
+            self._wg(x16[..., 16 * ci:16 * ci + 16], g_c0, taps, dW, Cin * 49, 1, Cout, 7, self.wws, dst_offset=ci * 49)
         red = ops.stat_buffer(Cout, g_c0.device)
         ops.channel_sum(g_c0, red)
         ops.cast_f64_to_f32(red, G(conv1.bias), Cout)
@@ -419,7 +449,7 @@ class Engine:
         ops.logsoftmax_bwd(g_logp, sv.out, g_l)
         bn10 = self.bn(m.bn10)
         nk = m.conv10.out_channels
-        ops.wgrad(sv.c10, g_l, T7, G(m.conv11.weight), nk * 49, 49, ncls, nk, self.wws, xf=self.relu_affine(bn10))
+        self._wg(sv.c10, g_l, T7, G(m.conv11.weight), nk * 49, 49, ncls, nk, self.wws, xf=self.relu_affine(bn10))
         NS = L.STAT_SLOTS
         red = ops.stat_buffer(16 + nk, dev)
         ops.channel_sum(g_l, red[:16 * NS])
@@ -429,7 +459,7 @@ class Engine:
         del g_l
         g_c10 = self._bn_bwd(bn10, g_a10, None, sv.c10, True, G, N * H * W)
         del g_a10
-        ops.wgrad(sv.d1o, g_c10, T7, G(m.conv10.weight), ip * 49, 49, nk, ip, self.wws)
+        self._wg(sv.d1o, g_c10, T7, G(m.conv10.weight), ip * 49, 49, nk, ip, self.wws)
         ops.channel_sum(g_c10, red[16 * NS:])
         ops.cast_f64_to_f32(red[16 * NS:], G(m.conv10.bias), nk)
         g = torch.empty(sv.d1o.shape, dtype=dt, device=dev)
@@ -465,7 +495,15 @@ class Engine:
             i = ids.index(id(last_param))
             hi = self.grad_offsets[self.grad_order[i][0]] + (self.grad_order[i][1].numel() + 3) // 4 * 4
             if hi > done[0]:
-                grad_ready(flat, done[0], hi)
+                if self._side_on:
+                    # flat[done:hi] is final once BOTH streams reach this point: hand the range over on a third
+                    # stream that waits for the two, so neither producer stalls for the exchange
+                    self.join.wait_stream(torch.cuda.current_stream(flat.device))
+                    self.join.wait_stream(self.side)
+                    with torch.cuda.stream(self.join):
+                        grad_ready(flat, done[0], hi)
+                else:
+                    grad_ready(flat, done[0], hi)
                 done[0] = hi
         return stage_done
 
@@ -530,7 +568,7 @@ class Engine:
         dt, dev, cnt = e.dtype, e.device, N * h * w
         psite = self.bn(post.ASPP_bn)
         g_cpost = self._bn_bwd(psite, g_post, None, cpost, True, G, cnt)
-        ops.wgrad(acat, g_cpost, T1, G(post.ASPP_conv.weight), 64 + Cn, 1, Cn, 64 + Cn, self.wws, xf=rec.xf)
+        self._wg(acat, g_cpost, T1, G(post.ASPP_conv.weight), 64 + Cn, 1, Cn, 64 + Cn, self.wws, xf=rec.xf)
         red = ops.stat_buffer(Cn, dev)
         ops.channel_sum(g_cpost, red)
         ops.cast_f64_to_f32(red, G(post.ASPP_conv.bias), Cn)
@@ -544,7 +582,7 @@ class Engine:
             g_cb = self._bn_bwd(site, g_acat[..., 16 * b:16 * b + 16], None, acat[..., 16 * b:16 * b + 16], True, G, cnt)
             kk = k * k
             taps = ops.conv_taps(k, dil, dil * (k // 2))
-            ops.wgrad(e, g_cb, taps, G(conv.weight), Cn * kk, kk, 16, Cn, self.wws)
+            self._wg(e, g_cb, taps, G(conv.weight), Cn * kk, kk, 16, Cn, self.wws)
             redb = ops.stat_buffer(16, dev)
             ops.channel_sum(g_cb, redb)
             ops.cast_f64_to_f32(redb, G(conv.bias), 16)
@@ -633,6 +671,7 @@ class Engine:
         flat, views = self._grad_views(dev)
         G = lambda p: views[id(p)]
         stage_done = self._stage_notifier(flat, grad_ready)
+        self._side_begin(dev)
         N, ncls, H, W = sv.out.shape
         ip = m.inplanes
         C3, C4, C5 = 8 * ip, 16 * ip, 32 * ip
@@ -661,6 +700,7 @@ class Engine:
         g_c0 = self._bn_bwd(bn1, g_x0, None, sv.c0, True, G, N * H * W)
         self.stem_bwd(m.conv1, sv.x16, g_c0, G)
         stage_done(self.grad_order[-1][1])
+        self._side_end(dev)
         return flat, views
 
     # ------------------------------------------------------------------ UResNet
@@ -748,23 +788,10 @@ class Engine:
         dev = sv.x.device
         self._rebind(sv)
         self.pack_all(dt, dev, "bwd")
-        flat = torch.empty(self.grad_numel, dtype=torch.float32, device=dev)
-        views = {}
-        for name, p in self.grad_order:
-            o = self.grad_offsets[name]
-            views[id(p)] = flat[o:o + p.numel()].view(p.shape)
+        flat, views = self._grad_views(dev)
         G = lambda p: views[id(p)]
-        done = [0]
-
-        def stage_done(last_param):
-            if grad_ready is None:
-                return
-            names = [n for n, _ in self.grad_order]
-            i = [id(p) for _, p in self.grad_order].index(id(last_param))
-            hi = self.grad_offsets[names[i]] + (self.grad_order[i][1].numel() + 3) // 4 * 4
-            if hi > done[0]:
-                grad_ready(flat, done[0], hi)
-                done[0] = hi
+        stage_done = self._stage_notifier(flat, grad_ready)
+        self._side_begin(dev)
 
         N, ncls, H, W = sv.out.shape
         ip = m.inplanes
@@ -775,7 +802,7 @@ class Engine:
         ops.logsoftmax_bwd(g_logp, sv.out, g_l)
         bn10 = self.bn(m.bn10)
         nk = m.conv10.out_channels
-        ops.wgrad(sv.c10, g_l, T7, G(m.conv11.weight), nk * 49, 49, ncls, nk, self.wws, xf=self.relu_affine(bn10))
+        self._wg(sv.c10, g_l, T7, G(m.conv11.weight), nk * 49, 49, ncls, nk, self.wws, xf=self.relu_affine(bn10))
         NS = L.STAT_SLOTS
         red = ops.stat_buffer(16 + nk, dev)
         ops.channel_sum(g_l, red[:16 * NS])
@@ -787,7 +814,7 @@ class Engine:
         del g_l
         g_c10 = self._bn_bwd(bn10, g_a10, None, sv.c10, True, G, N * H * W)
         del g_a10
-        ops.wgrad(sv.d1o, g_c10, T7, G(m.conv10.weight), ip * 49, 49, nk, ip, self.wws)
+        self._wg(sv.d1o, g_c10, T7, G(m.conv10.weight), ip * 49, 49, nk, ip, self.wws)
         ops.channel_sum(g_c10, red[16 * NS:])
         ops.cast_f64_to_f32(red[16 * NS:], G(m.conv10.bias), nk)
         g = torch.empty(sv.d1o.shape, dtype=dt, device=dev)
@@ -815,6 +842,7 @@ class Engine:
         g_c0 = self._bn_bwd(bn1, g_x0, None, sv.c0, True, G, N * H * W)
         self.stem_bwd(m.conv1, sv.x16, g_c0, G)
         stage_done(self.grad_order[-1][1])
+        self._side_end(dev)
         return flat, views
 
     # ------------------------------------------------------------------ dispatch
