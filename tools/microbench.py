@@ -35,7 +35,9 @@ if what.startswith("conv"):
     st = torch.zeros(32 * 2 * Cout, dtype=torch.float64, device=dev)
     xf = aff(Cin) if "noxf" not in sys.argv else None
     stats = st if "nostats" not in sys.argv else None
-    fn = lambda: ops.conv(x, wp, y, ops.conv_taps(k, 1, k // 2), Cout, xf=xf, stats=stats)
+    hint = max([int(a[4:]) for a in sys.argv if a.startswith("hint")] + [0])
+    ctaps = ops.conv_taps(k, 1, k // 2)
+    fn = lambda: ops.conv(x, wp, y, ctaps, Cout, xf=xf, stats=stats, tile_hint=hint)
     nbytes = x.numel() * 2 + y.numel() * 2
     flops = 2.0 * N * HW * HW * Cin * Cout * k * k
 elif what.startswith("wgrad"):

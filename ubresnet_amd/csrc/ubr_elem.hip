@@ -77,6 +77,7 @@ __global__ __launch_bounds__(256) void tail_fwd_kernel(long npix, int CU, const 
   ldconst<CPU>(s2, ix.c, a2); ldconst<CPU>(t2, ix.c, b2); ldconst<CPU>(m2p, ix.c, m2);
   const bool byp = sb != nullptr;
   if (byp) { ldconst<CPU>(sb, ix.c, ab); ldconst<CPU>(tb, ix.c, bb); ldconst<CPU>(mbp, ix.c, mb); }
+#pragma unroll 2
   for (long p = ix.p; p < npix; p += ix.pstep) {
     float v[CPU], s[CPU], o[CPU];
     ldunit<T>(c2, p, c2_ps, ix.c, v);
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(const TailB k) {
 #pragma unroll
     for (int e = 0; e < CPU; ++e) acc[qn][e] = 0.f;
 
+#pragma unroll 2
   for (long p = ix.p; p < k.npix; p += ix.pstep) {
     float g[CPU], o[CPU], c2[CPU], cb[CPU];
     ldunit<T>(k.go, p, k.go_ps, ix.c, g);
@@ -183,6 +185,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnB k) {
   float acc[2][CPU];
 #pragma unroll
   for (int e = 0; e < CPU; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
+#pragma unroll 2
   for (long p = ix.p; p < k.npix; p += ix.pstep) {
     float g[CPU], c[CPU], r[CPU];
     ldunit<T>(k.ga, p, k.ga_ps, ix.c, g);
@@ -217,6 +220,7 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(long npix, int C, int 
   float acc[1][CPU];
 #pragma unroll
   for (int e = 0; e < CPU; ++e) acc[0][e] = 0.f;
+#pragma unroll 2
   for (long p = ix.p; p < npix; p += ix.pstep) {
     float v[CPU];
     ldunit<T>(g, p, g_ps, ix.c, v);
@@ -305,6 +309,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const PoolK k) {
   float sc[CPU], sh[CPU], lo[CPU], sb[CPU];
   if (xf) { ldconst<CPU>(k.scale, ix.c, sc); ldconst<CPU>(k.shift, ix.c, sh); ldconst<CPU>(k.lo, ix.c, lo); ldconst<CPU>(k.sub, ix.c, sb); }
   const long npix = (long)k.N * k.OH * k.OW;
+#pragma unroll 2
   for (long p = ix.p; p < npix; p += ix.pstep) {
     const int ox = (int)(p % k.OW);
     const long r = p / k.OW;
@@ -347,6 +352,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const PoolK k) {
   if (xf) { ldconst<CPU>(k.scale, ix.c, sc); ldconst<CPU>(k.shift, ix.c, sh); ldconst<CPU>(k.lo, ix.c, lo); ldconst<CPU>(k.sub, ix.c, sb); }
   const long npix = (long)k.N * k.H * k.W;
   const int s = k.stride;
+#pragma unroll 2
   for (long p = ix.p; p < npix; p += ix.pstep) {
     const int jx = (int)(p % k.W);
     const long r = p / k.W;
@@ -407,6 +413,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_s2_kernel(const PoolK k) {
   float sc[CPU], sh[CPU], lo[CPU], sb[CPU];
   if (xf) { ldconst<CPU>(k.scale, ix.c, sc); ldconst<CPU>(k.shift, ix.c, sh); ldconst<CPU>(k.lo, ix.c, lo); ldconst<CPU>(k.sub, ix.c, sb); }
   const long npix = (long)k.N * k.OH * k.OW;
+#pragma unroll 2
   for (long p = ix.p; p < npix; p += ix.pstep) {
     const int ox = (int)(p % k.OW);
     const long r = p / k.OW;

@@ -195,24 +195,33 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgK k) {
 #pragma unroll
           for (int a = 0; a < MA; ++a) A[a] = sc_frag32(p + a * 64, k.pixbG);
         }
+        // Taps beyond ntaps (toff = 0) are computed and discarded: no branch.  The taps go in chunks of TC: all of a
+        // chunk's LDS fragment reads are issued first, then its MFMAs, so a read's latency hides under the
+        // previous MFMAs instead of being waited for tap by tap.
+        constexpr int TC = (TPG == 25) ? 5 : 1;   // (chunking the 9-tap kernels measured slower: their loops are short enough)
 #pragma unroll
-        for (int t = 0; t < TPG; ++t) {
-          {   // taps beyond ntaps (toff = 0) are computed and discarded: no branch, so the LDS reads of tap t+1
-              // can be issued under the MFMAs of tap t
+        for (int tc = 0; tc < TPG; tc += TC) {
+          uint4 B[TC][NBW];
+#pragma unroll
+          for (int tt = 0; tt < TC; ++tt)
 #pragma unroll
             for (int b = 0; b < NBW; ++b) {
-              uint4 B;
               if constexpr (CPU == 8) {
-                const char* p = xl + (r * k.S * k.HW + (8 * q + (l16 >> 2)) * k.S) * k.pixbX + toff[t] + (l16 & 3) * 8 + (nb0 + b) * 32;
-                B = tr_frag16(p, 4 * k.S * k.pixbX);
+                const char* p = xl + (r * k.S * k.HW + (8 * q + (l16 >> 2)) * k.S) * k.pixbX + toff[tc + tt] + (l16 & 3) * 8 + (nb0 + b) * 32;
+                B[tt][b] = tr_frag16(p, 4 * k.S * k.pixbX);
               } else {
-                const char* p = xl + (r * k.S * k.HW + (ks * 16 + 4 * q) * k.S) * k.pixbX + toff[t] + l16 * 4 + (nb0 + b) * 64;
-                B = sc_frag32(p, k.S * k.pixbX);
+                const char* p = xl + (r * k.S * k.HW + (ks * 16 + 4 * q) * k.S) * k.pixbX + toff[tc + tt] + l16 * 4 + (nb0 + b) * 64;
+                B[tt][b] = sc_frag32(p, k.S * k.pixbX);
               }
-#pragma unroll
-              for (int a = 0; a < MA; ++a) acc[t][a][b] = mma_step<T>(acc[t][a][b], A[a], B);
             }
-          }
+          if constexpr (TC > 1) __builtin_amdgcn_sched_barrier(0);   // keep the reads grouped ahead of the MFMAs (the scheduler would re-pair them)
+#pragma unroll
+          for (int tt = 0; tt < TC; ++tt)
+#pragma unroll
+            for (int b = 0; b < NBW; ++b)
+#pragma unroll
+              for (int a = 0; a < MA; ++a) acc[tc + tt][a][b] = mma_step<T>(acc[tc + tt][a][b], A[a], B[tt][b]);
+          if constexpr (TC > 1) __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
