@@ -195,6 +195,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgK k) {
 #pragma unroll
           for (int a = 0; a < MA; ++a) A[a] = sc_frag32(p + a * 64, k.pixbG);
         }
+        // this lane's LDS offset inside row r; kept opaque so that the compiler adds the (scalar) tap offset at each
+        // read instead of hoisting one address register per tap out of the row loop (50 VGPRs for 25 taps)
+        int xrow;
+        if constexpr (CPU == 8) xrow = (r * k.S * k.HW + (8 * q + (l16 >> 2)) * k.S) * k.pixbX + (l16 & 3) * 8;
+        else xrow = (r * k.S * k.HW + (ks * 16 + 4 * q) * k.S) * k.pixbX + l16 * 4;
+        asm volatile("" : "+v"(xrow));
         // Taps beyond ntaps (toff = 0) are computed and discarded: no branch.  The taps go in chunks of TC: all of a
         // chunk's LDS fragment reads are issued first, then its MFMAs, so a read's latency hides under the
         // previous MFMAs instead of being waited for tap by tap.
@@ -207,11 +213,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgK k) {
 #pragma unroll
             for (int b = 0; b < NBW; ++b) {
               if constexpr (CPU == 8) {
-                const char* p = xl + (r * k.S * k.HW + (8 * q + (l16 >> 2)) * k.S) * k.pixbX + toff[tc + tt] + (l16 & 3) * 8 + (nb0 + b) * 32;
-                B[tt][b] = tr_frag16(p, 4 * k.S * k.pixbX);
+                B[tt][b] = tr_frag16(xl + (xrow + toff[tc + tt] + (nb0 + b) * 32), 4 * k.S * k.pixbX);
               } else {
-                const char* p = xl + (r * k.S * k.HW + (ks * 16 + 4 * q) * k.S) * k.pixbX + toff[tc + tt] + l16 * 4 + (nb0 + b) * 64;
-                B[tt][b] = sc_frag32(p, k.S * k.pixbX);
+                B[tt][b] = sc_frag32(xl + (xrow + toff[tc + tt] + (nb0 + b) * 64), k.S * k.pixbX);
               }
             }
           if constexpr (TC > 1) __builtin_amdgcn_sched_barrier(0);   // keep the reads grouped ahead of the MFMAs (the scheduler would re-pair them)
