@@ -103,7 +103,7 @@ def _declare(lib):
     lib.ubr_conv.argtypes = [C.POINTER(ConvDesc), vp]
     lib.ubr_conv_last_config.argtypes = [C.POINTER(C.c_int)] * 3
     lib.ubr_conv_last_config.restype = None
-    lib.ubr_wgrad_last_config.argtypes = [C.POINTER(C.c_int)] * 4
+    lib.ubr_wgrad_last_config.argtypes = [C.POINTER(C.c_int)] * 5
     lib.ubr_wgrad_last_config.restype = None
     lib.ubr_pack_weights.argtypes = [i32, vp, vp, i32, i32, i32, i32, i64, i64, i32, C.POINTER(C.c_int32), vp]
     lib.ubr_pack_weights_batched.argtypes = [i32, vp, i32, vp]

@@ -51,8 +51,17 @@ __device__ __forceinline__ uint4 sc_frag32(const char* p0, int pstride) {
 // NSPLIT = true : the 4 waves split the cin fragments (N), every wave walks all rows: a 64 x 64-channel tile
 //                 with 9 taps costs the same 144 accumulator registers per wave as a K-split 32 x 32 tile but
 //                 re-stages G and X half as often per flop and needs no cross-wave reduction (C >= 64 layers).
-template <typename T, int MA, int NB, int TPG, bool NSPLIT>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgK k) {
+// Input-halo staging slots (16-byte items) per thread.  The software-pipelined tile loop keeps one tile's loads in
+// registers across the MFMA phase, so slots are sized for the common geometry of each variant (stride 1, dilation 1,
+// 8-row tiles when waves split rows, 4-row tiles when they split channels, 7x7 for the 25-tap kernel) instead of the
+// worst case; the planner shrinks the tile height for dilated / strided layers until their halo fits.
+// BIGX variants (9-tap, Cout tile 16 only: the ASPP branches and the column-expanded stem) carry 12 slots.
+__host__ __device__ constexpr int wgrad_xslots(bool nsplit, int tpg, int nb, int cpu, bool bigx) {
+  return (bigx ? 12 : (nsplit ? 7 : (tpg == 25 ? 5 : (nb == 1 ? 3 : 6)))) * (8 / cpu);
+}
+
+template <typename T, int MA, int NB, int TPG, bool NSPLIT, bool BIGX>
+__global__ __launch_bounds__(256, (TPG == 25 ? 2 : 1)) void wgrad_kernel(const WgK k) {
   constexpr int NBW = NSPLIT ? NB / 4 : NB;     // cin fragments owned by one wave
   static_assert(!NSPLIT || NB % 4 == 0, "N-split needs a multiple of 4 cin fragments");
   constexpr int CPU = ET<T>::CPU;
@@ -85,7 +94,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgK k) {
   // of its channels sit in registers.  The tile loop is software-pipelined: the global loads of tile i+1 are
   // issued into registers (gv/xv) right before the MFMA phase of tile i and written to LDS after it. ----
   constexpr int GS = (NSPLIT ? 4 : 8) * 32 * UG / 256;       // G slots per thread (TH <= 4 / 8)
-  constexpr int XS = (CPU == 8) ? 12 : (NSPLIT ? 16 : 12);   // X slots per thread (host checks the halo fits)
+  constexpr int XS = wgrad_xslots(NSPLIT, TPG, NB, CPU, BIGX);     // X slots per thread (host shrinks the tile until the halo fits)
   float xsub[CPU], xsc[CPU], xsh[CPU], xlo[CPU];
   if (has_xf) {
     const int ch0 = ci0 + (tid % UX) * CPU;
@@ -281,7 +290,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgK k) {
   }
 }
 
-struct WPlan { int MA, NB, TPG, TH, HH, HW, pixbG, pixbX, x_off, tiles_x, tiles_y, ntiles, nsplit, gy, gz, nsplit_mode; size_t lds; };
+struct WPlan { int MA, NB, TPG, TH, HH, HW, pixbG, pixbX, x_off, tiles_x, tiles_y, ntiles, nsplit, gy, gz, nsplit_mode, bigx; size_t lds; };
 
 static int wgrad_plan(const ubr_wgrad_desc* d, WPlan* p) {
   UBR_CHECK(d != nullptr, "ubr_wgrad: null descriptor");
@@ -310,15 +319,19 @@ static int wgrad_plan(const ubr_wgrad_desc* d, WPlan* p) {
     // input halo fits the per-thread staging slots (large dilations / stride 2 / fp32 have the biggest halos)
     const int cpu = ubr_cpu(d->dtype);
     const int th0 = p->TH;
+    p->bigx = 0;
     for (;;) {
-      const int xs = (cpu == 8) ? 12 : (p->nsplit_mode ? 16 : 12);
+      const int xs = wgrad_xslots(p->nsplit_mode != 0, TPG, NB, cpu, p->bigx != 0);
       const int ux = NB * 16 / cpu;
       p->HH = (p->TH - 1) * d->S + 1 + (dymax - dymin);
       p->HW = 31 * d->S + 1 + (dxmax - dxmin);
       if ((long)p->HH * p->HW * ux <= 256L * xs) break;
+      // more slots before a shorter tile, where the wide-slot variant exists
+      if (!p->bigx && !p->nsplit_mode && MA == 1 && TPG == 9) { p->bigx = 1; continue; }
       if (p->TH > 1) { p->TH /= 2; continue; }
       if (p->nsplit_mode) { p->nsplit_mode = 0; MA = 2; NB = 2; p->TH = d->S == 1 ? 8 : 4; continue; }
-      if (NB > 1) { NB = 1; p->TH = th0 > 4 ? 4 : th0; continue; }
+      if (NB > 1) { NB = 1; p->bigx = 0; p->TH = th0 > 4 ? 4 : th0; continue; }
+      if (MA > 1 && TPG == 9) { MA = 1; p->TH = th0 > 4 ? 4 : th0; continue; }
       ubr_set_error("ubr_wgrad: halo of %d x %d pixels does not fit the staging registers", p->HH, p->HW);
       return UBR_EINVAL;
     }
@@ -350,9 +363,9 @@ static int wgrad_plan(const ubr_wgrad_desc* d, WPlan* p) {
   return UBR_OK;
 }
 
-template <typename T, int MA, int NB, int TPG, bool NSPLIT>
+template <typename T, int MA, int NB, int TPG, bool NSPLIT, bool BIGX = false>
 int wlaunch(const WgK& k, const WPlan& p, hipStream_t st) {
-  auto fn = wgrad_kernel<T, MA, NB, TPG, NSPLIT>;
+  auto fn = wgrad_kernel<T, MA, NB, TPG, NSPLIT, BIGX>;
   if (p.lds > 64 * 1024) {
     static thread_local size_t maxset = 0;
     if (p.lds > maxset) {
@@ -368,8 +381,12 @@ int wlaunch(const WgK& k, const WPlan& p, hipStream_t st) {
 
 template <typename T>
 int wdispatch(const WgK& k, const WPlan& p, hipStream_t st) {
-#define UBR_WCASE(ma, nb, tpg) if (!p.nsplit_mode && p.MA == ma && p.NB == nb && p.TPG == tpg) return wlaunch<T, ma, nb, tpg, false>(k, p, st);
-#define UBR_NCASE(tpg) if (p.nsplit_mode && p.MA == 4 && p.NB == 4 && p.TPG == tpg) return wlaunch<T, 4, 4, tpg, true>(k, p, st);
+  if (p.bigx && !p.nsplit_mode && p.MA == 1 && p.TPG == 9) {
+    if (p.NB == 1) return wlaunch<T, 1, 1, 9, false, true>(k, p, st);
+    if (p.NB == 2) return wlaunch<T, 1, 2, 9, false, true>(k, p, st);
+  }
+#define UBR_WCASE(ma, nb, tpg) if (!p.bigx && !p.nsplit_mode && p.MA == ma && p.NB == nb && p.TPG == tpg) return wlaunch<T, ma, nb, tpg, false>(k, p, st);
+#define UBR_NCASE(tpg) if (!p.bigx && p.nsplit_mode && p.MA == 4 && p.NB == 4 && p.TPG == tpg) return wlaunch<T, 4, 4, tpg, true>(k, p, st);
   UBR_NCASE(1) UBR_NCASE(4) UBR_NCASE(9)
 #undef UBR_NCASE
   UBR_WCASE(1, 1, 1) UBR_WCASE(1, 2, 1) UBR_WCASE(2, 1, 1) UBR_WCASE(2, 2, 1)
@@ -426,19 +443,20 @@ extern "C" int ubr_wgrad_plan(const ubr_wgrad_desc* d, int32_t* nsplit, int64_t*
   return UBR_OK;
 }
 
-static thread_local int g_last_wgrad_cfg[4] = {0, 0, 0, 0};
-extern "C" void ubr_wgrad_last_config(int* ma, int* nb, int* tpg, int* nsplit_mode) {
+static thread_local int g_last_wgrad_cfg[5] = {0, 0, 0, 0, 0};
+extern "C" void ubr_wgrad_last_config(int* ma, int* nb, int* tpg, int* nsplit_mode, int* bigx) {
   if (ma) *ma = g_last_wgrad_cfg[0];
   if (nb) *nb = g_last_wgrad_cfg[1];
   if (tpg) *tpg = g_last_wgrad_cfg[2];
   if (nsplit_mode) *nsplit_mode = g_last_wgrad_cfg[3];
+  if (bigx) *bigx = g_last_wgrad_cfg[4];
 }
 
 extern "C" int ubr_wgrad(const ubr_wgrad_desc* d, void* stream) {
   WPlan p{};
   int rc = wgrad_plan(d, &p);
   if (rc != UBR_OK) return rc;
-  g_last_wgrad_cfg[0] = p.MA; g_last_wgrad_cfg[1] = p.NB; g_last_wgrad_cfg[2] = p.TPG; g_last_wgrad_cfg[3] = p.nsplit_mode;
+  g_last_wgrad_cfg[0] = p.MA; g_last_wgrad_cfg[1] = p.NB; g_last_wgrad_cfg[2] = p.TPG; g_last_wgrad_cfg[3] = p.nsplit_mode; g_last_wgrad_cfg[4] = p.bigx;
   const int esz = ubr_esize(d->dtype);
   UBR_CHECK(d->x.p && d->g.p && d->slabs, "ubr_wgrad: null tensor");
   UBR_CHECK(d->nsplit == p.nsplit, "ubr_wgrad: nsplit %d does not match plan %d", d->nsplit, p.nsplit);
