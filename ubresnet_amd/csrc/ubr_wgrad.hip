@@ -311,7 +311,7 @@ static int wgrad_plan(const ubr_wgrad_desc* d, WPlan* p) {
   p->nsplit_mode = 0;
   p->TH = d->S == 1 ? 8 : 4;   // rows beyond GH are zero-filled, so small grids stay correct
   if (TPG <= 9 && d->Cout % 64 == 0 && d->Cin % 64 == 0) {   // wide layers: 64 x 64 channel tile, waves split cin
-    MA = 4; NB = 4; p->nsplit_mode = 1;
+    MA = (TPG == 9) ? 2 : 4; NB = 4; p->nsplit_mode = 1;   // 9 taps: 32 x 64 tile keeps the kernel under 256 VGPRs (2 waves/SIMD)
     p->TH = d->S == 1 ? 4 : 2;
   }
   {
@@ -352,7 +352,7 @@ static int wgrad_plan(const ubr_wgrad_desc* d, WPlan* p) {
   p->gz = ubr_cdiv(d->ntaps, TPG);
   // workgroups in flight: thin layers want many (tiny slabs, latency hiding by occupancy); for wide layers
   // every extra split adds a full |dW| slab to write and re-read, so stay near one or two per CU
-  int target = (p->nsplit_mode ? 384 : 1024) / (p->gy * p->gz);
+  int target = (p->nsplit_mode ? 512 : 1024) / (p->gy * p->gz);
   if (target < 1) target = 1;
   // bound slab memory: at most 64 MiB of partials per launch
   const size_t slab_bytes = (size_t)d->ntaps * d->Cout * d->Cin * sizeof(float);
@@ -386,8 +386,8 @@ int wdispatch(const WgK& k, const WPlan& p, hipStream_t st) {
     if (p.NB == 2) return wlaunch<T, 1, 2, 9, false, true>(k, p, st);
   }
 #define UBR_WCASE(ma, nb, tpg) if (!p.bigx && !p.nsplit_mode && p.MA == ma && p.NB == nb && p.TPG == tpg) return wlaunch<T, ma, nb, tpg, false>(k, p, st);
-#define UBR_NCASE(tpg) if (!p.bigx && p.nsplit_mode && p.MA == 4 && p.NB == 4 && p.TPG == tpg) return wlaunch<T, 4, 4, tpg, true>(k, p, st);
-  UBR_NCASE(1) UBR_NCASE(4) UBR_NCASE(9)
+#define UBR_NCASE(ma, tpg) if (!p.bigx && p.nsplit_mode && p.MA == ma && p.NB == 4 && p.TPG == tpg) return wlaunch<T, ma, 4, tpg, true>(k, p, st);
+  UBR_NCASE(4, 1) UBR_NCASE(4, 4) UBR_NCASE(2, 9)
 #undef UBR_NCASE
   UBR_WCASE(1, 1, 1) UBR_WCASE(1, 2, 1) UBR_WCASE(2, 1, 1) UBR_WCASE(2, 2, 1)
   UBR_WCASE(1, 1, 4) UBR_WCASE(1, 2, 4) UBR_WCASE(2, 1, 4) UBR_WCASE(2, 2, 4)
