@@ -13,6 +13,7 @@
 //
 // Workgroup = 256 threads = 4 waves.  Tile = TH x TW output pixels (TW = 16*TWF) x TN = 16*NT
 // output channels.  Wave w owns FW pixel fragments (16 px each) x NT channel fragments.
+#include <stdlib.h>
 #include "ubr_common.h"
 #include "ubr_host.h"
 
@@ -68,8 +69,12 @@ template <> __device__ __forceinline__ void load4<f16_t>(const char* p, float* v
   v[0] = (float)h[0]; v[1] = (float)h[1]; v[2] = (float)h[2]; v[3] = (float)h[3];
 }
 
-template <typename T, int FW, int NT, int TWF>
-__global__ __launch_bounds__(256, ((NT == 4 && FW <= 2) ? 4 : 2)) void conv_igemm_kernel(const ConvK k) {
+// register slots of the cin-block pipeline (PIPE): one block's halo and weight items per thread, sized for 3x3 taps
+__host__ __device__ constexpr int conv_pipe_hslots(int fw, int twf) { return ((4 * fw / twf + 2) * (twf * 16 + 2) * 4 + 255) / 256; }
+__host__ __device__ constexpr int conv_pipe_wslots(int nt) { return (36 * nt * 16 + 255) / 256; }
+
+template <typename T, int FW, int NT, int TWF, bool PIPE>
+__global__ __launch_bounds__(256, ((NT == 4 && FW <= 2 && !PIPE) ? 4 : 2)) void conv_igemm_kernel(const ConvK k) {
   constexpr int TN = NT * 16;
   constexpr int F = 4 * FW;
   constexpr int TH = F / TWF;
@@ -131,6 +136,90 @@ __global__ __launch_bounds__(256, ((NT == 4 && FW <= 2) ? 4 : 2)) void conv_igem
   const int nitems = k.HH * (int)k.rw;
   const bool has_xf = k.in_scale != nullptr;
 
+  if constexpr (PIPE) {
+    // Cin-block pipeline (wide layers, >= 2 cin blocks): the global loads of block b+1 (halo and weight slab) are
+    // issued into registers right before the MFMA phase of block b and written to LDS after it, so a block's load
+    // round trip hides under the previous block's matrix work instead of being waited for at the top of each block.
+    constexpr int HS = conv_pipe_hslots(FW, TWF), WS = conv_pipe_wslots(NT);
+    uint4 hv[HS], wv[WS];
+    unsigned hok = 0u;
+    const int c = tid & (k.UPB - 1);
+    const int hy00 = (int)__umulhi((unsigned)tid, k.rw_magic);
+    const int j00 = tid - hy00 * (int)k.rw;
+    const int nw = 4 * k.steps * TN;
+    auto load_blk = [&](int blk) {
+      const int ch0 = (blk * k.UPB + c) * CPU;
+      const char* xc = xn + (long)ch0 * ESZ;
+      int hy = hy00, j = j00;
+      int goff = (hy0 + hy) * k.x_sy32 + (hx0 + (j >> k.lgUPB)) * k.x_sx32;
+      hok = 0u;
+#pragma unroll
+      for (int u = 0; u < HS; ++u) {
+        const int iy = hy0 + hy, ix = hx0 + (j >> k.lgUPB);
+        const bool ok = (tid + u * 256 < nitems) && (unsigned)iy < (unsigned)k.H && (unsigned)ix < (unsigned)k.W;
+        hv[u] = make_uint4(0u, 0u, 0u, 0u);
+        if (ok) { hv[u] = ldg16(xc + goff); hok |= 1u << u; }
+        j += k.step_j; hy += k.step_hy; goff += k.step_goff;
+        if (j >= (int)k.rw) { j -= (int)k.rw; hy += 1; goff += k.wrap_goff; }
+      }
+      const int boff = blk * k.UPB * k.Cout_pad + n0;
+#pragma unroll
+      for (int u = 0; u < WS; ++u) {
+        const int i = tid + u * 256;
+        wv[u] = make_uint4(0u, 0u, 0u, 0u);
+        if (i < nw) {
+          const int src = wsrc[i / TN];
+          if (src >= 0) wv[u] = ldg16(k.w + ((long)(src + boff + (i % TN))) * 16);
+        }
+      }
+    };
+    auto store_blk = [&](int blk) {
+      const int ch0 = (blk * k.UPB + c) * CPU;
+      float xsub[CPU], xsc[CPU], xsh[CPU], xlo[CPU];
+      if (has_xf) {
+#pragma unroll
+        for (int e = 0; e < CPU; ++e) { xsub[e] = k.in_sub[ch0 + e]; xsc[e] = k.in_scale[ch0 + e]; xsh[e] = k.in_shift[ch0 + e]; xlo[e] = k.in_lo[ch0 + e]; }
+      }
+#pragma unroll
+      for (int u = 0; u < HS; ++u) {
+        const int i = tid + u * 256;
+        uint4 v = hv[u];
+        if (has_xf && ((hok >> u) & 1u)) {
+          float f[CPU];
+          ET<T>::unpack(v, f);
+#pragma unroll
+          for (int e = 0; e < CPU; ++e) f[e] = fmaxf(fmaf(f[e] - xsub[e], xsc[e], xsh[e]), xlo[e]);
+          v = ET<T>::pack(f);
+        }
+        if (i < nitems) *reinterpret_cast<uint4*>(halo + (i >> k.lgUPB) * k.pixb + c * 16) = v;
+      }
+#pragma unroll
+      for (int u = 0; u < WS; ++u) {
+        const int i = tid + u * 256;
+        if (i < nw) *reinterpret_cast<uint4*>(wl + (long)i * 16) = wv[u];
+      }
+    };
+    load_blk(0);
+    for (int blk = 0; blk < k.nblk; ++blk) {
+      if (blk) __syncthreads();          // previous block's fragments fully read
+      store_blk(blk);
+      __syncthreads();
+      if (blk + 1 < k.nblk) load_blk(blk + 1);
+      for (int s = 0; s < k.steps; ++s) {
+        const int off = tbl[4 * s + q];
+        uint4 wf[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          wf[j] = *reinterpret_cast<const uint4*>(wl + (((4 * s + q) * TN) + j * 16 + l16) * 16);
+#pragma unroll
+        for (int i = 0; i < FW; ++i) {
+          const uint4 a = *reinterpret_cast<const uint4*>(halo + fragbase[i] + off);
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = mma_step<T>(acc[i][j], wf[j], a);
+        }
+      }
+    }
+  } else
   for (int blk = 0; blk < k.nblk; ++blk) {
     if (blk) __syncthreads();
     // ---- stage the input halo (transform + zero padding) ----
@@ -324,9 +413,9 @@ static const TileCfg kCfgs[] = {
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
-template <typename T, int FW, int NT, int TWF>
-int launch_cfg(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
-  auto fn = conv_igemm_kernel<T, FW, NT, TWF>;
+template <typename T, int FW, int NT, int TWF, bool PIPE>
+int launch_one(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
+  auto fn = conv_igemm_kernel<T, FW, NT, TWF, PIPE>;
   if (lds > 64 * 1024) {
     static thread_local size_t maxset = 0;  // per instantiation
     if (lds > maxset) {
@@ -338,6 +427,17 @@ int launch_cfg(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
   hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, k);
   UBR_LAUNCH_CHECK("ubr_conv");
   return UBR_OK;
+}
+
+// the cin-block pipeline exists for the 64-cout tiles, when a block's items fit its register slots
+template <typename T, int FW, int NT, int TWF>
+int launch_cfg(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
+  if constexpr (NT == 4) {
+    static const bool enabled = [] { const char* e = getenv("UBR_CONV_PIPE"); return !e || atoi(e) != 0; }();
+    if (enabled && k.nblk >= 2 && k.HH * (int)k.rw <= 256 * conv_pipe_hslots(FW, TWF) && 4 * k.steps * NT * 16 <= 256 * conv_pipe_wslots(NT))
+      return launch_one<T, FW, NT, TWF, true>(k, grid, lds, st);
+  }
+  return launch_one<T, FW, NT, TWF, false>(k, grid, lds, st);
 }
 
 template <typename T>
