@@ -101,7 +101,7 @@ def _declare(lib):
     lib.ubr_stem_wgrad_workspace.restype = C.c_int64
     lib.ubr_stem_wgrad_workspace.argtypes = [i32] * 5
     lib.ubr_conv.argtypes = [C.POINTER(ConvDesc), vp]
-    lib.ubr_conv_last_config.argtypes = [C.POINTER(C.c_int)] * 3
+    lib.ubr_conv_last_config.argtypes = [C.POINTER(C.c_int)] * 4
     lib.ubr_conv_last_config.restype = None
     lib.ubr_wgrad_last_config.argtypes = [C.POINTER(C.c_int)] * 5
     lib.ubr_wgrad_last_config.restype = None

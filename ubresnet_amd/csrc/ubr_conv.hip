@@ -397,6 +397,7 @@ __global__ __launch_bounds__(256, ((NT == 4 && FW <= 2 && !PIPE) ? 4 : 2)) void 
   }
 }
 
+static thread_local int g_last_conv_cfg[4] = {0, 0, 0, 0};   // FW, NT, TWF, PIPE of this thread's last launch
 struct TileCfg { int FW, NT, TWF; };
 // id -> config; keep in sync with the dispatch switch
 static const TileCfg kCfgs[] = {
@@ -435,8 +436,9 @@ int launch_cfg(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
   if constexpr (NT == 4) {
     static const bool enabled = [] { const char* e = getenv("UBR_CONV_PIPE"); return !e || atoi(e) != 0; }();
     if (enabled && k.nblk >= 2 && k.HH * (int)k.rw <= 256 * conv_pipe_hslots(FW, TWF) && 4 * k.steps * NT * 16 <= 256 * conv_pipe_wslots(NT))
-      return launch_one<T, FW, NT, TWF, true>(k, grid, lds, st);
+      { g_last_conv_cfg[3] = 1; return launch_one<T, FW, NT, TWF, true>(k, grid, lds, st); }
   }
+  g_last_conv_cfg[3] = 0;
   return launch_one<T, FW, NT, TWF, false>(k, grid, lds, st);
 }
 
@@ -486,11 +488,11 @@ static bool plan_for(const ubr_conv_desc* d, int cfg, int dymin, int dymax, int 
 
 }  // namespace
 
-static thread_local int g_last_conv_cfg[3] = {0, 0, 0};
-extern "C" void ubr_conv_last_config(int* fw, int* nt, int* twf) {
+extern "C" void ubr_conv_last_config(int* fw, int* nt, int* twf, int* pipe) {
   if (fw) *fw = g_last_conv_cfg[0];
   if (nt) *nt = g_last_conv_cfg[1];
   if (twf) *twf = g_last_conv_cfg[2];
+  if (pipe) *pipe = g_last_conv_cfg[3];
 }
 
 extern "C" int ubr_conv(const ubr_conv_desc* d, void* stream) {

@@ -245,9 +245,11 @@ class Engine:
     def _side_begin(self, dev):
         """Weight gradients depend on nothing downstream, so they run on a second HIP stream next to the
         dgrad / BatchNorm-backward chain: the low-resolution layers launch too few workgroups to fill 256 CUs
-        on their own.  Disabled while the launch profiler is attached (per-kernel times must not overlap)."""
+        on their own.  UBR_WGRAD_STREAM=0 serialises everything on one stream (clean per-kernel timings); the
+        launch profiler otherwise times kernels under the same two-stream contention as the real step (and as
+        rocprofv3 sees them)."""
         import os
-        self._side_on = dev.type == "cuda" and ops._prof is None and os.environ.get("UBR_WGRAD_STREAM", "1") != "0"
+        self._side_on = dev.type == "cuda" and os.environ.get("UBR_WGRAD_STREAM", "1") != "0"
         if self._side_on and self.side is None:
             self.side = torch.cuda.Stream(device=dev)
             self.join = torch.cuda.Stream(device=dev)
