@@ -12,6 +12,7 @@
 // A workgroup owns (cout tile, cin tile, tap group), walks pixel tiles with a grid stride
 // (split-K), keeps all its dW partials in registers, and finally writes ONE fp32 slab;
 // ubr_wgrad_reduce sums slabs in fixed order -> bitwise reproducible, no float atomics.
+#include <stdlib.h>
 #include "ubr_common.h"
 #include "ubr_host.h"
 
@@ -308,6 +309,7 @@ static int wgrad_plan(const ubr_wgrad_desc* d, WPlan* p) {
   int TPG = d->ntaps <= 1 ? 1 : d->ntaps <= 4 ? 4 : d->ntaps <= 9 ? 9 : 25;
   int MA = (d->Cout % 32 == 0) ? 2 : 1, NB = (d->Cin % 32 == 0) ? 2 : 1;
   if (TPG == 25) { MA = 1; NB = 1; }
+  if (TPG == 9 && MA == 2 && NB == 2) NB = 1;   // the 32 x 32 x 9-tap tile needs 320 VGPRs (one wave per SIMD); 32 x 16 fits two: 89 -> 64 us
   p->nsplit_mode = 0;
   p->TH = d->S == 1 ? 8 : 4;   // rows beyond GH are zero-filled, so small grids stay correct
   if (TPG <= 9 && d->Cout % 64 == 0 && d->Cin % 64 == 0) {   // wide layers: 64 x 64 channel tile, waves split cin
