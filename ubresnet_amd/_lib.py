@@ -165,7 +165,14 @@ def check(rc: int, what: str = ""):
         raise RuntimeError("ubresnet_amd HIP call failed (%d) %s: %s" % (rc, what, msg))
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr() -> int:
+    """raw hipStream_t of torch's current stream on the current device (every launch asks: the Python-level
+    torch.cuda.current_stream() costs ~8 us per call, the raw query well under one)"""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -60,6 +60,7 @@ class Engine:
         self.side = None
         self.join = None
         self._side_on = False
+        self._evs, self._ev_next, self._main = [], 0, None
         self.bn_sites: List[BNSite] = []
         self._bn_of: Dict[int, BNSite] = {}
         for m in model.modules():
@@ -253,6 +254,9 @@ class Engine:
         if self._side_on and self.side is None:
             self.side = torch.cuda.Stream(device=dev)
             self.join = torch.cuda.Stream(device=dev)
+        if self._side_on:
+            self._main = torch.cuda.current_stream(dev)
+            self._ev_next = 0
 
     def _side_end(self, dev):
         if self._side_on:
@@ -262,13 +266,22 @@ class Engine:
     def _wg(self, x, g, *args, **kw):
         if not self._side_on:
             return ops.wgrad(x, g, *args, **kw)
-        main = torch.cuda.current_stream(x.device)
-        self.side.wait_stream(main)
-        with torch.cuda.stream(self.side):
-            ops.wgrad(x, g, *args, **kw)
+        # side stream waits for everything queued on the compute stream so far (x and g are produced there); the
+        # launch goes straight to the side stream's handle -- no stream-context switch, one pooled event per call
+        ev = self._event()
+        ev.record(self._main)
+        self.side.wait_event(ev)
+        ops.wgrad(x, g, *args, stream=self.side, **kw)
         # the caching allocator must not hand these blocks to later main-stream kernels while the side stream reads them
         x.record_stream(self.side)
         g.record_stream(self.side)
+
+    def _event(self):
+        i = self._ev_next
+        if i == len(self._evs):
+            self._evs.append(torch.cuda.Event())
+        self._ev_next = i + 1
+        return self._evs[i]
 
     def _bn_bwd(self, site: BNSite, ga, ga2, c, relu, G, cnt):
         """backward through a = relu(bn(c)) (or bn only): returns g_c; writes dgamma/dbeta"""

@@ -163,6 +163,21 @@ def pack_weights(src: torch.Tensor, dtype: torch.dtype, M: int, K: int, sm: int,
     return dst
 
 
+_TAP_CACHE = {}
+
+
+def _tap_arrays(taps):
+    """ctypes images of a tap list, built once per distinct list (the tap lists are a handful of module constants)"""
+    key = tuple(taps)
+    r = _TAP_CACHE.get(key)
+    if r is None:
+        n = len(key)
+        r = ((C.c_int8 * n)(*[t[0] for t in key]), (C.c_int8 * n)(*[t[1] for t in key]), (C.c_uint8 * n)(*[t[2] for t in key]),
+             max(t[2] for t in key))
+        _TAP_CACHE[key] = r
+    return r
+
+
 @_timed("conv")
 def conv(x: torch.Tensor, wp: torch.Tensor, y: torch.Tensor, taps, Cout: int, S: int = 1, iy0: int = 0, ix0: int = 0,
          xf: Optional[Affine] = None, bias: Optional[torch.Tensor] = None, addend: Optional[torch.Tensor] = None,
@@ -182,10 +197,10 @@ def conv(x: torch.Tensor, wp: torch.Tensor, y: torch.Tensor, taps, Cout: int, S:
     d.ntaps = len(taps)
     if not 1 <= len(taps) <= L.MAX_TAPS:
         raise RuntimeError("conv: %d taps unsupported" % len(taps))
-    for i, (dy, dx, wt) in enumerate(taps):
-        d.dy[i], d.dx[i], d.wt[i] = dy, dx, wt
-        if wt >= wp.shape[0]:
-            raise RuntimeError("conv: tap index %d outside packed image" % wt)
+    dy_a, dx_a, wt_a, wt_max = _tap_arrays(taps)
+    C.memmove(d.dy, dy_a, len(taps)); C.memmove(d.dx, dx_a, len(taps)); C.memmove(d.wt, wt_a, len(taps))
+    if wt_max >= wp.shape[0]:
+        raise RuntimeError("conv: tap index %d outside packed image" % wt_max)
     d.S, d.iy0, d.ix0 = S, iy0, ix0
     if logsoftmax:
         assert y.dtype == torch.float32 and y.is_contiguous() and y.shape[1] == Cout
@@ -229,11 +244,24 @@ class WgradWorkspace:
         return self.buf
 
 
+_TAP_CACHE_W = {}
+
+
+def _tap_arrays_w(taps):
+    key = tuple(taps)
+    r = _TAP_CACHE_W.get(key)
+    if r is None:
+        n = len(key)
+        r = ((C.c_int8 * n)(*[t[0] for t in key]), (C.c_int8 * n)(*[t[1] for t in key]), (C.c_int32 * n)(*[t[2] for t in key]), n)
+        _TAP_CACHE_W[key] = r
+    return r
+
+
 def wgrad(x: torch.Tensor, g: torch.Tensor, taps, dst: torch.Tensor, sm: int, sk: int, Cout_valid: int, Cin_valid: int,
           ws: WgradWorkspace, S: int = 1, iy0: int = 0, ix0: int = 0, xf: Optional[Affine] = None, accumulate: bool = False,
-          dst_offset: int = 0):
+          dst_offset: int = 0, stream=None):
     """dst[co*sm + ci*sk + tapidx] (+)= sum_pixels g[p][co] * xform(x)[p*S + tap][ci]
-    taps: [(dy, dx, tapidx into the PyTorch weight layout)]"""
+    taps: [(dy, dx, tapidx into the PyTorch weight layout)]; stream: torch.cuda.Stream to launch on (default: current)"""
     d = L.WgradDesc()
     d.dtype = L.dtype_id(x.dtype)
     N, H, W, Cin = x.shape
@@ -244,8 +272,8 @@ def wgrad(x: torch.Tensor, g: torch.Tensor, taps, dst: torch.Tensor, sm: int, sk
     d.GH, d.GW, d.Cout = g.shape[1], g.shape[2], g.shape[3]
     d.g = _tv(g)
     d.ntaps = len(taps)
-    for i, (dy, dx, _) in enumerate(taps):
-        d.dy[i], d.dx[i] = dy, dx
+    dy_a, dx_a, _, _ = _tap_arrays_w(taps)
+    C.memmove(d.dy, dy_a, len(taps)); C.memmove(d.dx, dx_a, len(taps))
     d.S, d.iy0, d.ix0 = S, iy0, ix0
     nsplit, nbytes = C.c_int32(0), C.c_int64(0)
     lib = L.lib()
@@ -253,19 +281,19 @@ def wgrad(x: torch.Tensor, g: torch.Tensor, taps, dst: torch.Tensor, sm: int, sk
     slabs = ws.get(nbytes.value, x.device)
     d.slabs = slabs.data_ptr()
     d.nsplit = nsplit.value
-    st = L.stream_ptr()
+    st = L.stream_ptr() if stream is None else stream.cuda_stream
     if _prof is not None:
         e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-        e0.record()
+        e0.record(stream)
     L.check(lib.ubr_wgrad(C.byref(d), st), "wgrad")
     if _prof is not None:
-        e1.record()
-    idx = (C.c_int32 * len(taps))(*[t[2] for t in taps])
+        e1.record(stream)
+    idx = _tap_arrays_w(taps)[2]
     assert dst.dtype == torch.float32
     L.check(lib.ubr_wgrad_reduce(slabs.data_ptr(), nsplit.value, len(taps), d.Cout, Cin, Cout_valid, Cin_valid,
                                  dst.data_ptr() + 4 * dst_offset, sm, sk, idx, 1 if accumulate else 0, st), "wgrad_reduce")
     if _prof is not None:
-        e2.record()
+        e2.record(stream)
         a, b, c, dd, bx = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
         lib.ubr_wgrad_last_config(C.byref(a), C.byref(b), C.byref(c), C.byref(dd), C.byref(bx))
         kern = "wgrad_kernel<%s, %d, %d, %d, %s, %s>" % (_DT_NAME[x.dtype], a.value, b.value, c.value, "true" if dd.value else "false",
