@@ -29,15 +29,19 @@ class GradAllReducer:
         self.pending_hi = None
         self.flat = None
         self.works = []
+        self.wait_events = []
         self.use_avg = dist.is_initialized() and dist.get_backend(group) == "nccl"
         model._grad_ready_hook = self._hook
 
-    # called by the executor on the compute stream: flat[lo:hi] is final
-    def _hook(self, flat: torch.Tensor, lo: int, hi: int):
+    # called by the executor on the compute stream: flat[lo:hi] is final once the compute stream AND every event in
+    # wait_events (work the executor queued on its other streams) have been reached
+    def _hook(self, flat: torch.Tensor, lo: int, hi: int, wait_events=()):
         if self.world == 1 and not self.force:
             return
         if self.flat is not flat:
             self.flat, self.pending_lo, self.pending_hi = flat, lo, lo
+            self.wait_events = []
+        self.wait_events.extend(wait_events)
         self.pending_hi = hi
         last = hi >= flat.numel()
         if self.pending_hi - self.pending_lo >= self.bucket_elems or last:
@@ -51,11 +55,16 @@ class GradAllReducer:
         op = dist.ReduceOp.AVG if self.use_avg else dist.ReduceOp.SUM
         if chunk.is_cuda:
             if self.stream is None:
-                self.stream = torch.cuda.Stream(device=chunk.device)
+                # high priority: its own hardware queue (a normal-priority stream can alias the compute stream's queue
+                # and the all-reduce would then serialise with the backward kernels instead of overlapping them)
+                self.stream = torch.cuda.Stream(device=chunk.device, priority=-1)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(chunk.device))
             with torch.cuda.stream(self.stream):
                 self.stream.wait_event(ev)
+                for e in self.wait_events:
+                    self.stream.wait_event(e)
+                self.wait_events = []
                 self.works.append(dist.all_reduce(chunk, op=op, group=self.group, async_op=True))
         else:
             self.works.append(dist.all_reduce(chunk, op=op, group=self.group, async_op=True))
