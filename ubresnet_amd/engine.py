@@ -60,6 +60,7 @@ class Engine:
         self.side = None
         self._side_on = False
         self._evs, self._ev_next, self._main = [], 0, None
+        self._red_buf, self._red_off, self._red_elems = None, 0, 0
         self.bn_sites: List[BNSite] = []
         self._bn_of: Dict[int, BNSite] = {}
         for m in model.modules():
@@ -241,6 +242,27 @@ class Engine:
         rec.blk, rec.x, rec.c1, rec.c2, rec.cb, rec.out, rec.xf_in = blk, x, c1, c2, cb, out, xf_in
         return rec
 
+    # ------------------------------------------------------------------ backward reduction arena
+    def _red_begin(self, dev):
+        """one zeroed fp64 arena per backward pass for every striped reduction buffer (one memset instead of ~45)"""
+        if self._red_elems == 0:
+            NS = L.STAT_SLOTS
+            tot = 0
+            for s_ in self.bn_sites:
+                tot += 2 * s_.C * NS
+            self._red_elems = 2 * tot + 64 * NS * 8      # BN sites (block tails take 2 sites' worth) + head/stem/bias sums
+        self._red_buf = torch.empty(self._red_elems, dtype=torch.float64, device=dev)
+        ops.zero_(self._red_buf)
+        self._red_off = 0
+
+    def _red(self, n, dev):
+        k = L.STAT_SLOTS * n
+        if self._red_buf is None or self._red_off + k > self._red_buf.numel() or self._red_buf.device != dev:
+            return ops.stat_buffer(n, dev)           # outside a backward pass, or arena exhausted
+        t = self._red_buf[self._red_off:self._red_off + k]
+        self._red_off += k
+        return t
+
     # ------------------------------------------------------------------ weight-gradient side stream
     def _side_begin(self, dev):
         """Weight gradients depend on nothing downstream, so they run on a second HIP stream next to the
@@ -290,7 +312,7 @@ class Engine:
 
     def _bn_bwd(self, site: BNSite, ga, ga2, c, relu, G, cnt):
         """backward through a = relu(bn(c)) (or bn only): returns g_c; writes dgamma/dbeta"""
-        red = ops.stat_buffer(2 * site.C, c.device)
+        red = self._red(2 * site.C, c.device)
         ops.bn_bwd_reduce(ga, ga2, c, site.scale, site.shift, site.mean, site.invstd, relu, red)
         k = torch.empty(2 * site.C, dtype=torch.float32, device=c.device)
         k1, k2 = k[:site.C], k[site.C:]
@@ -329,7 +351,7 @@ class Engine:
         byp = cb is not None
         bnb = self.bn(blk.bnpass) if byp else None
         NS = L.STAT_SLOTS
-        red = ops.stat_buffer((4 if byp else 2) * Cout, dev)
+        red = self._red((4 if byp else 2) * Cout, dev)
         red2 = red[:2 * Cout * NS]
         redb = red[2 * Cout * NS:] if byp else None
         ops.block_tail_bwd_reduce(go, go2, out, c2, bn2.scale, bn2.shift, bn2.mean, bn2.invstd,
@@ -442,7 +464,7 @@ class Engine:
         taps = [(ky - 3, 0, 7 * ky) for ky in range(7)]
         for ci in range(Cin):
             self._wg(x16[..., 16 * ci:16 * ci + 16], g_c0, taps, dW, Cin * 49, 1, Cout, 7, self.wws, dst_offset=ci * 49)
-        red = ops.stat_buffer(Cout, g_c0.device)
+        red = self._red(Cout, g_c0.device)
         ops.channel_sum(g_c0, red)
         ops.cast_f64_to_f32(red, G(conv1.bias), Cout)
 
@@ -471,7 +493,7 @@ class Engine:
         nk = m.conv10.out_channels
         self._wg(sv.c10, g_l, T7, G(m.conv11.weight), nk * 49, 49, ncls, nk, self.wws, xf=self.relu_affine(bn10))
         NS = L.STAT_SLOTS
-        red = ops.stat_buffer(16 + nk, dev)
+        red = self._red(16 + nk, dev)
         ops.channel_sum(g_l, red[:16 * NS])
         ops.cast_f64_to_f32(red[:16 * NS], G(m.conv11.bias), ncls, stride=16)
         g_a10 = torch.empty((N, H, W, nk), dtype=dt, device=dev)
@@ -588,7 +610,7 @@ class Engine:
         psite = self.bn(post.ASPP_bn)
         g_cpost = self._bn_bwd(psite, g_post, None, cpost, True, G, cnt)
         self._wg(acat, g_cpost, T1, G(post.ASPP_conv.weight), 64 + Cn, 1, Cn, 64 + Cn, self.wws, xf=rec.xf)
-        red = ops.stat_buffer(Cn, dev)
+        red = self._red(Cn, dev)
         ops.channel_sum(g_cpost, red)
         ops.cast_f64_to_f32(red, G(post.ASPP_conv.bias), Cn)
         g_acat = torch.empty(acat.shape, dtype=dt, device=dev)
@@ -602,7 +624,7 @@ class Engine:
             kk = k * k
             taps = ops.conv_taps(k, dil, dil * (k // 2))
             self._wg(e, g_cb, taps, G(conv.weight), Cn * kk, kk, 16, Cn, self.wws)
-            redb = ops.stat_buffer(16, dev)
+            redb = self._red(16, dev)
             ops.channel_sum(g_cb, redb)
             ops.cast_f64_to_f32(redb, G(conv.bias), 16)
             ops.conv(g_cb, self.packed(conv.weight, dt, "dgrad"), g_e, ops.conv_dgrad_taps_s1(k, dil, dil * (k // 2)), Cn, addend=g_e)
@@ -691,6 +713,7 @@ class Engine:
         G = lambda p: views[id(p)]
         stage_done = self._stage_notifier(flat, grad_ready)
         self._side_begin(dev)
+        self._red_begin(dev)
         N, ncls, H, W = sv.out.shape
         ip = m.inplanes
         C3, C4, C5 = 8 * ip, 16 * ip, 32 * ip
@@ -720,6 +743,7 @@ class Engine:
         self.stem_bwd(m.conv1, sv.x16, g_c0, G)
         stage_done(self.grad_order[-1][1])
         self._side_end(dev)
+        self._red_buf = None
         return flat, views
 
     # ------------------------------------------------------------------ UResNet
@@ -811,6 +835,7 @@ class Engine:
         G = lambda p: views[id(p)]
         stage_done = self._stage_notifier(flat, grad_ready)
         self._side_begin(dev)
+        self._red_begin(dev)
 
         N, ncls, H, W = sv.out.shape
         ip = m.inplanes
@@ -823,7 +848,7 @@ class Engine:
         nk = m.conv10.out_channels
         self._wg(sv.c10, g_l, T7, G(m.conv11.weight), nk * 49, 49, ncls, nk, self.wws, xf=self.relu_affine(bn10))
         NS = L.STAT_SLOTS
-        red = ops.stat_buffer(16 + nk, dev)
+        red = self._red(16 + nk, dev)
         ops.channel_sum(g_l, red[:16 * NS])
         ops.cast_f64_to_f32(red[:16 * NS], G(m.conv11.bias), ncls, stride=16)
         g_a10 = torch.empty((N, H, W, nk), dtype=dt, device=dev)
@@ -862,6 +887,7 @@ class Engine:
         self.stem_bwd(m.conv1, sv.x16, g_c0, G)
         stage_done(self.grad_order[-1][1])
         self._side_end(dev)
+        self._red_buf = None
         return flat, views
 
     # ------------------------------------------------------------------ dispatch
