@@ -39,7 +39,7 @@ print("per stream/queue busy ms:", {k: round(v / 1e6, 3) for k, v in by.items()}
 # per-stream, per-kernel-family totals of the analysed step
 fam = collections.defaultdict(float)
 for s, e, n, q in step:
-    key = n.split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")[:60]
+    key = n.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:60]
     fam[(q, key)] += (e - s) / 1e6
 for (q, key), v in sorted(fam.items(), key=lambda kv: -kv[1])[:40]:
     print("stream %s  %-62s %.3f ms" % (q, key, v))
