@@ -220,14 +220,17 @@ int ubr_block_tail_bwd_apply(int dtype, int64_t npix, int C, const void* go, int
  * nn.MaxPool2d(3, stride, padding=1)  (models/ub_uresnet.py:44 stride 2; ASPP_ResNet.py:222 stride 1)
  * forward reads the (optionally transformed) input, writes the pooled map and optionally the
  * transformed input itself (`xcopy`, the skip tensor x0 of models/ub_uresnet.py:96);
- * backward gathers g_pooled through the recomputed arg-max (first maximum in scan order,
- * as ATen) and adds `g_extra` (gradient arriving through the skip connection).
+ * backward gathers g_pooled through the arg-max (first maximum in scan order, as ATen) and adds
+ * `g_extra` (gradient arriving through the skip connection).  `argmax` (optional, uint8
+ * [N][OH][OW][C], tap index ky*3+kx): forward records it, and a stride-2 backward given it reads
+ * four gradient units and four index words per 2x2 input block instead of re-scanning windows;
+ * without it backward recomputes the arg-max from x.
  * ---------------------------------------------------------------------------------------- */
 int ubr_maxpool_fwd(int dtype, int N, int H, int W, int C, int stride, const void* x, int64_t x_ps,
-                    ubr_chan_affine xf, void* pooled, int64_t p_ps, void* xcopy, int64_t xc_ps, void* stream);
+                    ubr_chan_affine xf, void* pooled, int64_t p_ps, void* xcopy, int64_t xc_ps, uint8_t* argmax, void* stream);
 int ubr_maxpool_bwd(int dtype, int N, int H, int W, int C, int stride, const void* x, int64_t x_ps,
                     ubr_chan_affine xf, const void* g_pooled, int64_t gp_ps, const void* g_extra, int64_t ge_ps,
-                    void* gx, int64_t gx_ps, void* stream);
+                    void* gx, int64_t gx_ps, const uint8_t* argmax, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Head / loss

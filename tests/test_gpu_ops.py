@@ -411,7 +411,8 @@ def test_maxpool(dt, stride):
     pooled = torch.empty((N, p.shape[2], p.shape[3], C), dtype=dt, device=DEV)
     cat = torch.zeros((N, H, W, 2 * C), dtype=dt, device=DEV)
     xcopy = cat[..., C:] if stride == 2 else None
-    ops.maxpool_fwd(cd, aff, pooled, xcopy, stride)
+    amax = torch.empty(pooled.shape, dtype=torch.uint8, device=DEV) if stride == 2 else None
+    ops.maxpool_fwd(cd, aff, pooled, xcopy, stride, argmax=amax)
     torch.cuda.synchronize()
     close(nchw(pooled), p.detach(), tol(dt), "pool fwd")
     if stride == 2:
@@ -424,6 +425,13 @@ def test_maxpool(dt, stride):
     # anyway; compare where the input is positive
     mask = (xr.detach() > 0).float()
     close(nchw(gx) * mask, (xr.grad + ge) * mask, tol(dt), "pool bwd")
+    if stride == 2:
+        # same gradient from the arg-max the forward saved (bit-identical to the re-scanning kernel: same first-max rule)
+        gx2 = torch.empty_like(gx)
+        ops.maxpool_bwd(cd, aff, nhwc(gp, dt), nhwc(ge, dt), gx2, stride, argmax=amax)
+        torch.cuda.synchronize()
+        assert torch.equal(gx2, gx)
+        assert int(amax.max()) <= 8
 
 
 @pytest.mark.parametrize("dt", DTS)

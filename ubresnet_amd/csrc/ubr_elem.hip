@@ -299,6 +299,7 @@ struct PoolK {
   const void* gp; long gp_ps;
   const void* ge; long ge_ps;
   void* gx; long gx_ps;
+  uint8_t* amax;          // [N][OH][OW][C] tap index (ky*3+kx) of the window maximum: written by forward, read by backward
 };
 
 template <typename T>
@@ -316,8 +317,9 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const PoolK k) {
     const int oy = (int)(r % k.OH);
     const int n = (int)(r / k.OH);
     float m[CPU];
+    int am[CPU];
 #pragma unroll
-    for (int e = 0; e < CPU; ++e) m[e] = -FLT_MAX;
+    for (int e = 0; e < CPU; ++e) { m[e] = -FLT_MAX; am[e] = -1; }
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
       const int iy = oy * k.stride - 1 + ky;
@@ -333,13 +335,92 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const PoolK k) {
 #pragma unroll
           for (int e = 0; e < CPU; ++e) v[e] = fmaxf(fmaf(v[e] - sb[e], sc[e], sh[e]), lo[e]);
         }
+        if (k.amax != nullptr) {
 #pragma unroll
-        for (int e = 0; e < CPU; ++e) m[e] = fmaxf(m[e], v[e]);
+          for (int e = 0; e < CPU; ++e)
+            if (am[e] < 0 || v[e] > m[e]) { m[e] = v[e]; am[e] = ky * 3 + kx; }   // strict >: first maximum wins (ATen)
+        } else {
+#pragma unroll
+          for (int e = 0; e < CPU; ++e) m[e] = fmaxf(m[e], v[e]);
+        }
         // each stride-2 window owns the 2x2 input pixels (2oy..2oy+1, 2ox..2ox+1) = taps ky,kx in {1,2}
         if (k.xcopy != nullptr && ky >= 1 && kx >= 1) stunit<T>(k.xcopy, ip, k.xc_ps, ix.c, v);
       }
     }
     stunit<T>(k.pooled, p, k.p_ps, ix.c, m);
+    if (k.amax != nullptr) {
+      uint8_t* a = k.amax + p * k.C + (long)ix.c * CPU;
+      if constexpr (CPU == 8) {
+        *reinterpret_cast<uint2*>(a) = make_uint2((unsigned)am[0] | ((unsigned)am[1] << 8) | ((unsigned)am[2] << 16) | ((unsigned)am[3] << 24),
+                                                  (unsigned)am[4] | ((unsigned)am[5] << 8) | ((unsigned)am[6] << 16) | ((unsigned)am[7] << 24));
+      } else {
+        *reinterpret_cast<unsigned*>(a) = (unsigned)am[0] | ((unsigned)am[1] << 8) | ((unsigned)am[2] << 16) | ((unsigned)am[3] << 24);
+      }
+    }
+  }
+}
+
+// stride-2 backward from the saved arg-max: one thread per pooled pixel owns the 2x2 input pixels and looks at the
+// (up to) four windows that overlap them -- four gradient units and four index words instead of 36 transformed loads.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_s2_amax_kernel(const PoolK k) {
+  constexpr int CPU = ET<T>::CPU;
+  UnitIdx<T> ix(k.CU);
+  const long npix = (long)k.N * k.OH * k.OW;
+#pragma unroll 2
+  for (long p = ix.p; p < npix; p += ix.pstep) {
+    const int ox = (int)(p % k.OW);
+    const long r = p / k.OW;
+    const int oy = (int)(r % k.OH);
+    const int n = (int)(r / k.OH);
+    float g[2][2][CPU];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        if (k.ge != nullptr) ldunit<T>(k.ge, ((long)n * k.H + 2 * oy + a) * k.W + 2 * ox + b, k.ge_ps, ix.c, g[a][b]);
+        else {
+#pragma unroll
+          for (int e = 0; e < CPU; ++e) g[a][b][e] = 0.f;
+        }
+      }
+#pragma unroll
+    for (int wy = 0; wy < 2; ++wy) {
+      if (oy + wy >= k.OH) continue;
+#pragma unroll
+      for (int wx = 0; wx < 2; ++wx) {
+        if (ox + wx >= k.OW) continue;
+        const long wp = ((long)n * k.OH + oy + wy) * k.OW + ox + wx;
+        float gp[CPU];
+        ldunit<T>(k.gp, wp, k.gp_ps, ix.c, gp);
+        unsigned am[CPU];
+        const uint8_t* ap = k.amax + wp * k.C + (long)ix.c * CPU;
+        if constexpr (CPU == 8) {
+          const uint2 w = *reinterpret_cast<const uint2*>(ap);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { am[e] = (w.x >> (8 * e)) & 0xffu; am[4 + e] = (w.y >> (8 * e)) & 0xffu; }
+        } else {
+          const unsigned w = *reinterpret_cast<const unsigned*>(ap);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) am[e] = (w >> (8 * e)) & 0xffu;
+        }
+        // tap (ky,kx) of window (wy,wx) is owned pixel (a,b) = (2wy-1+ky, 2wx-1+kx)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const int ky = a + 1 - 2 * wy, kx = b + 1 - 2 * wx;
+            if (ky < 0 || ky > 2 || kx < 0 || kx > 2) continue;
+#pragma unroll
+            for (int e = 0; e < CPU; ++e)
+              if (am[e] == (unsigned)(ky * 3 + kx)) g[a][b][e] += gp[e];
+          }
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) stunit<T>(k.gx, ((long)n * k.H + 2 * oy + a) * k.W + 2 * ox + b, k.gx_ps, ix.c, g[a][b]);
   }
 }
 
@@ -659,7 +740,7 @@ extern "C" int ubr_zero(void* p, int64_t bytes, void* stream) {
 
 static int pool_common(bool bwd, int dtype, int N, int H, int W, int C, int stride, const void* x, int64_t x_ps, ubr_chan_affine xf,
                        void* pooled, int64_t p_ps, void* xcopy, int64_t xc_ps,
-                       const void* gp, int64_t gp_ps, const void* ge, int64_t ge_ps, void* gx, int64_t gx_ps, void* stream) {
+                       const void* gp, int64_t gp_ps, const void* ge, int64_t ge_ps, void* gx, int64_t gx_ps, uint8_t* amax, void* stream) {
   const char* who = bwd ? "ubr_maxpool_bwd" : "ubr_maxpool_fwd";
   UBR_CHECK(N > 0 && H > 0 && W > 0 && (stride == 1 || stride == 2), "%s: bad extents", who);
   const int OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
@@ -670,6 +751,8 @@ static int pool_common(bool bwd, int dtype, int N, int H, int W, int C, int stri
   PoolK k{};
   k.N = N; k.H = H; k.W = W; k.OH = OH; k.OW = OW; k.C = C; k.CU = C / ubr_cpu(dtype); k.stride = stride;
   k.x = x; k.x_ps = x_ps; k.sub = xf.sub; k.scale = xf.scale; k.shift = xf.shift; k.lo = xf.lo;
+  k.amax = amax;
+  if (amax) UBR_CHECK(C % ubr_cpu(dtype) == 0 && (((uintptr_t)amax) & 7) == 0, "%s: argmax buffer must be 8-byte aligned", who);
   if (!bwd) {
     UBR_TRY(check_nhwc(who, dtype, npix_out, C, pooled, p_ps));
     if (xcopy) {
@@ -684,7 +767,10 @@ static int pool_common(bool bwd, int dtype, int N, int H, int W, int C, int stri
     if (ge) UBR_TRY(check_nhwc(who, dtype, npix_in, C, ge, ge_ps));
     UBR_TRY(check_nhwc(who, dtype, npix_in, C, gx, gx_ps));
     k.gp = gp; k.gp_ps = gp_ps; k.ge = ge; k.ge_ps = ge_ps; k.gx = gx; k.gx_ps = gx_ps;
-    if (stride == 2 && H % 2 == 0 && W % 2 == 0) {
+    if (amax && stride == 2 && H % 2 == 0 && W % 2 == 0) {
+      const int blocks = pick_blocks(npix_out, k.CU);
+      UBR_DT_SWITCH(dtype, hipLaunchKernelGGL(maxpool_bwd_s2_amax_kernel<TT>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, k));
+    } else if (stride == 2 && H % 2 == 0 && W % 2 == 0) {
       const int blocks = pick_blocks(npix_out, k.CU);
       UBR_DT_SWITCH(dtype, hipLaunchKernelGGL(maxpool_bwd_s2_kernel<TT>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, k));
     } else {
@@ -696,11 +782,12 @@ static int pool_common(bool bwd, int dtype, int N, int H, int W, int C, int stri
   return UBR_OK;
 }
 extern "C" int ubr_maxpool_fwd(int dtype, int N, int H, int W, int C, int stride, const void* x, int64_t x_ps,
-                               ubr_chan_affine xf, void* pooled, int64_t p_ps, void* xcopy, int64_t xc_ps, void* stream) {
-  return pool_common(false, dtype, N, H, W, C, stride, x, x_ps, xf, pooled, p_ps, xcopy, xc_ps, nullptr, 0, nullptr, 0, nullptr, 0, stream);
+                               ubr_chan_affine xf, void* pooled, int64_t p_ps, void* xcopy, int64_t xc_ps, uint8_t* argmax, void* stream) {
+  return pool_common(false, dtype, N, H, W, C, stride, x, x_ps, xf, pooled, p_ps, xcopy, xc_ps, nullptr, 0, nullptr, 0, nullptr, 0, argmax, stream);
 }
 extern "C" int ubr_maxpool_bwd(int dtype, int N, int H, int W, int C, int stride, const void* x, int64_t x_ps,
                                ubr_chan_affine xf, const void* g_pooled, int64_t gp_ps, const void* g_extra, int64_t ge_ps,
-                               void* gx, int64_t gx_ps, void* stream) {
-  return pool_common(true, dtype, N, H, W, C, stride, x, x_ps, xf, nullptr, 0, nullptr, 0, g_pooled, gp_ps, g_extra, ge_ps, gx, gx_ps, stream);
+                               void* gx, int64_t gx_ps, const uint8_t* argmax, void* stream) {
+  return pool_common(true, dtype, N, H, W, C, stride, x, x_ps, xf, nullptr, 0, nullptr, 0, g_pooled, gp_ps, g_extra, ge_ps, gx, gx_ps,
+                     const_cast<uint8_t*>(argmax), stream);
 }

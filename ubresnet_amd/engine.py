@@ -668,7 +668,8 @@ class Engine:
         self._finish_bn(bn1, N * H * W, training)
         cat1 = E(N, H, W, 2 * ip)
         p0 = E(N, H // 2, W // 2, ip)
-        ops.maxpool_fwd(c0, self.relu_affine(bn1), p0, cat1[..., ip:], 2)
+        amax = torch.empty((N, H // 2, W // 2, ip), dtype=torch.uint8, device=dev) if save else None   # window arg-max for the backward
+        ops.maxpool_fwd(c0, self.relu_affine(bn1), p0, cat1[..., ip:], 2, argmax=amax)
         cat2 = E(N, H // 2, W // 2, 4 * ip)
         cat3 = E(N, H // 4, W // 4, 8 * ip)
         cat4 = E(N, H // 8, W // 8, 3 * C3)
@@ -699,7 +700,7 @@ class Engine:
         c10, out = self.head_fwd(m, d1o, training, dt)
         if not save:
             return out, None
-        sv.x, sv.x16, sv.c0 = x, x16, c0
+        sv.x, sv.x16, sv.c0, sv.amax = x, x16, c0, amax
         sv.enc, sv.aspp, sv.dec = (r1, r2, r3, r4, r5), (a3, a4, a5), (d1, d2, d3, d4, d5)
         sv.d1o, sv.c10, sv.out, sv.dt = d1o, c10, out, dt
         return out, sv
@@ -738,7 +739,7 @@ class Engine:
         g = self.double_bwd(r1, g, gc2[..., 2 * ip:], G); stage_done(m.enc_layer1.res1.conv1.weight)
         bn1 = self.bn(m.bn1)
         g_x0 = torch.empty(sv.c0.shape, dtype=dt, device=dev)
-        ops.maxpool_bwd(sv.c0, self.relu_affine(bn1), g, gc1[..., ip:], g_x0, 2)
+        ops.maxpool_bwd(sv.c0, self.relu_affine(bn1), g, gc1[..., ip:], g_x0, 2, argmax=sv.amax)
         g_c0 = self._bn_bwd(bn1, g_x0, None, sv.c0, True, G, N * H * W)
         self.stem_bwd(m.conv1, sv.x16, g_c0, G)
         stage_done(self.grad_order[-1][1])
@@ -779,7 +780,8 @@ class Engine:
         self._finish_bn(bn1, N * H * W, training)
         cat1 = E(N, H, W, 2 * ip)
         p0 = E(N, H // 2, W // 2, ip)
-        ops.maxpool_fwd(c0, self.relu_affine(bn1), p0, cat1[..., ip:], 2)
+        amax = torch.empty((N, H // 2, W // 2, ip), dtype=torch.uint8, device=dev) if save else None   # window arg-max for the backward
+        ops.maxpool_fwd(c0, self.relu_affine(bn1), p0, cat1[..., ip:], 2, argmax=amax)
 
         # encoder: each level's output is written into the skip half of the matching concat buffer
         cat2 = E(N, H // 2, W // 2, 4 * ip)
@@ -817,7 +819,7 @@ class Engine:
                  bias=m.conv11.bias, logsoftmax=True)
         if not save:
             return out, None
-        sv.x, sv.x16, sv.c0, sv.cat1, sv.p0 = x, x16, c0, cat1, p0
+        sv.x, sv.x16, sv.c0, sv.cat1, sv.p0, sv.amax = x, x16, c0, cat1, p0, amax
         sv.enc = (e1, e2, e3, e4, e5)
         sv.dec = (d1, d2, d3, d4, d5)
         sv.cats = (cat1, cat2, cat3, cat4, cat5)
@@ -882,7 +884,7 @@ class Engine:
         # ---- stem ----
         bn1 = self.bn(m.bn1)
         g_x0 = torch.empty(sv.c0.shape, dtype=dt, device=dev)
-        ops.maxpool_bwd(sv.c0, self.relu_affine(bn1), g, gc1[..., ip:], g_x0, 2)
+        ops.maxpool_bwd(sv.c0, self.relu_affine(bn1), g, gc1[..., ip:], g_x0, 2, argmax=sv.amax)
         g_c0 = self._bn_bwd(bn1, g_x0, None, sv.c0, True, G, N * H * W)
         self.stem_bwd(m.conv1, sv.x16, g_c0, G)
         stage_done(self.grad_order[-1][1])

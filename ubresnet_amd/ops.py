@@ -416,19 +416,24 @@ def block_tail_bwd_apply(go, go2, out, c2, scale2, shift2, mean2, invstd2, k1_2,
 # max pool
 # ------------------------------------------------------------------------------------------
 @_timed("maxpool_fwd")
-def maxpool_fwd(x, xf, pooled, xcopy, stride):
+def maxpool_fwd(x, xf, pooled, xcopy, stride, argmax=None):
+    """argmax: optional uint8 [N,OH,OW,C] receiving each window's arg-max tap (for maxpool_bwd)"""
     N, H, W, Cn = x.shape
+    if argmax is not None:
+        assert argmax.dtype == torch.uint8 and argmax.is_contiguous() and tuple(argmax.shape) == tuple(pooled.shape)
     L.check(L.lib().ubr_maxpool_fwd(L.dtype_id(x.dtype), N, H, W, Cn, stride, x.data_ptr(), _ps(x), _xf(xf),
                                     pooled.data_ptr(), _ps(pooled), L.ptr(xcopy), _ps(xcopy) if xcopy is not None else 0,
-                                    L.stream_ptr()), "maxpool_fwd")
+                                    L.ptr(argmax), L.stream_ptr()), "maxpool_fwd")
 
 
 @_timed("maxpool_bwd")
-def maxpool_bwd(x, xf, g_pooled, g_extra, gx, stride):
+def maxpool_bwd(x, xf, g_pooled, g_extra, gx, stride, argmax=None):
     N, H, W, Cn = x.shape
+    if argmax is not None:
+        assert argmax.dtype == torch.uint8 and argmax.is_contiguous() and tuple(argmax.shape) == tuple(g_pooled.shape)
     L.check(L.lib().ubr_maxpool_bwd(L.dtype_id(x.dtype), N, H, W, Cn, stride, x.data_ptr(), _ps(x), _xf(xf),
                                     g_pooled.data_ptr(), _ps(g_pooled), L.ptr(g_extra), _ps(g_extra) if g_extra is not None else 0,
-                                    gx.data_ptr(), _ps(gx), L.stream_ptr()), "maxpool_bwd")
+                                    gx.data_ptr(), _ps(gx), L.ptr(argmax), L.stream_ptr()), "maxpool_bwd")
 
 
 # ------------------------------------------------------------------------------------------
