@@ -135,6 +135,66 @@ def _grad_verdict(row):
     return ["grad %s: max-rel %.3e (fp32 floor %.3e), l2-rel %.3e, cos %.5f" % (n, emax, fmax, el2, cos)]
 
 
+def test_full_size_config1_matches_reference_summary(golden_dir):
+    """BASELINE.json configs[0] at its real size (UResNet ip16, B=2, 1x512x512, fp32): the fixture holds what the
+    reference's own code produced there -- 4096 sampled log-probabilities (eval and train mode), class counts and an
+    argmax hash, the loss, and for each of the 165 gradient tensors its L2 norm and 16 sampled entries."""
+    import hashlib
+    g = np.load(os.path.join(golden_dir, "uresnet_ip16_2x1x512x512_summary.npz"))
+    B, C, H, W, seed0, wseed = [int(v) for v in g["meta"]]
+    sd = O.seeded_state_dict(O.uresnet_schema(3, C, 16, 16), wseed)
+    x, lab, wgt = synthetic.make_batch(B, H, W, seed0)
+    m = _model(sd)
+    m.eval()
+    with torch.no_grad():
+        ev = m(torch.from_numpy(x).cuda()).cpu()
+    idx = g["sample_idx"]
+    ref = g["sample_logp_eval"]
+    scale = max(1.0, float(np.abs(ref).max()))
+    err = float(np.abs(ev.numpy().reshape(-1)[idx] - ref).max())
+    assert err <= 1e-4 * scale, "eval log-prob samples: %.3e (scale %.3e)" % (err, scale)   # measured 1.3e-6; north_star bar 1e-3
+    am = ev.argmax(1).numpy().astype(np.uint8)
+    nlow = len(g["low_margin_idx"])
+    if nlow == 0:
+        assert hashlib.sha256(am.tobytes()).hexdigest() == str(g["argmax_sha256_eval"]), "class map differs from the reference's"
+    assert np.abs(np.bincount(am.reshape(-1), minlength=3) - g["class_counts_eval"]).sum() <= 2 * nlow
+    # train step
+    m.train()
+    out = m.forward(torch.from_numpy(x).cuda())
+    loss = PixelWiseNLLLoss().forward(out, torch.from_numpy(lab).cuda(), torch.from_numpy(wgt).cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    ref_t = g["sample_logp_train"]
+    err_t = float(np.abs(out.detach().cpu().numpy().reshape(-1)[idx] - ref_t).max())
+    assert err_t <= 1e-4 * max(1.0, float(np.abs(ref_t).max())), "train log-prob samples: %.3e" % err_t   # measured 2e-6
+    assert abs(loss.item() - float(g["loss"])) <= 1e-4 * abs(float(g["loss"]))
+    # gradients: norms of all 165 tensors and the sampled entries.  The reference numbers are its fp32 CPU run, which
+    # is itself a few 1e-3 away from exact arithmetic on the ReLU-mask-sensitive tensors (see _grad_verdict), so the
+    # bar is 5e-3 on each norm and 2e-2 on the samples relative to the tensor's largest sampled entry.
+    params = dict(m.named_parameters())
+    bad = []
+    worst_norm = 0.0
+    for name, nref in zip([str(n) for n in g["grad_names"]], g["grad_norms"]):
+        gv = params[name].grad.detach().cpu().double().reshape(-1)
+        if name in ("conv1.bias", "conv10.bias"):        # analytically zero (a BatchNorm follows)
+            assert gv.abs().max().item() <= 1e-4
+            continue
+        nrm = float(torch.sqrt((gv * gv).sum()))
+        worst_norm = max(worst_norm, abs(nrm - float(nref)) / float(nref))
+        if abs(nrm - float(nref)) > 5e-3 * float(nref):          # measured worst 2.5e-4
+            bad.append("%s norm %.6e vs %.6e" % (name, nrm, float(nref)))
+        rs = np.random.RandomState(7)
+        sidx = np.sort(rs.choice(gv.numel(), size=min(16, gv.numel()), replace=False))
+        sref = g["gs__" + name].astype(np.float64)
+        sgot = gv.numpy()[sidx]
+        tol_abs = 2e-2 * max(float(np.abs(sref).max()), float(nref) / np.sqrt(gv.numel()))
+        if np.abs(sgot - sref).max() > tol_abs:
+            bad.append("%s samples max err %.3e (tol %.3e)" % (name, np.abs(sgot - sref).max(), tol_abs))
+    print("full-size config 1: eval sample err %.2e, train sample err %.2e, loss rel %.2e, worst grad-norm rel %.2e"
+          % (err / scale, err_t / max(1.0, float(np.abs(ref_t).max())), abs(loss.item() - float(g["loss"])) / abs(float(g["loss"])), worst_norm))
+    assert not bad, "; ".join(bad[:6])
+
+
 def test_gradients_dense_input_tight():
     """Same check on a dense noise image with the reference's init (gamma=1, beta=0).  Even here the
     fp32 CPU oracle is ~1e-2 from its fp64 evaluation on some tensors (ReLU mask flips through 52
