@@ -20,7 +20,8 @@ t0 = time.perf_counter()
 for _ in range(20): step()
 torch.cuda.synchronize()
 print("host-bound step: %.2f ms" % ((time.perf_counter() - t0) * 50))
+torch.autograd.set_multithreading_enabled(False)      # run the custom backward in this thread so cProfile sees it
 pr = cProfile.Profile(); pr.enable()
 for _ in range(10): step()
 torch.cuda.synchronize(); pr.disable()
-st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(22)
+st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(32)
