@@ -352,9 +352,12 @@ static int wgrad_plan(const ubr_wgrad_desc* d, WPlan* p) {
   p->ntiles = p->tiles_x * p->tiles_y * d->N;
   p->gy = (d->Cout / (MA * 16)) * (d->Cin / (NB * 16));
   p->gz = ubr_cdiv(d->ntaps, TPG);
-  // workgroups in flight: thin layers want many (tiny slabs, latency hiding by occupancy); for wide layers
-  // every extra split adds a full |dW| slab to write and re-read, so stay near one or two per CU
-  int target = (p->nsplit_mode ? 512 : 1024) / (p->gy * p->gz);
+  // One workgroup per CU.  More would finish a lone weight gradient sooner, but these kernels run on the side stream
+  // beside the dgrad chain and their long-lived workgroups (200+ VGPRs, grid-stride over tiles) must leave register
+  // file and LDS for the compute stream's kernels: 512 / 1024 workgroups cost the step 5 % (1077 vs 1136 img/s).
+  static const int tgt_n = [] { const char* e = getenv("UBR_WGRAD_TARGET_N"); return e ? atoi(e) : 256; }();
+  static const int tgt_k = [] { const char* e = getenv("UBR_WGRAD_TARGET_K"); return e ? atoi(e) : 256; }();
+  int target = (p->nsplit_mode ? tgt_n : tgt_k) / (p->gy * p->gz);
   if (target < 1) target = 1;
   // bound slab memory: at most 64 MiB of partials per launch
   const size_t slab_bytes = (size_t)d->ntaps * d->Cout * d->Cin * sizeof(float);

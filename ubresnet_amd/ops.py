@@ -279,6 +279,10 @@ def wgrad(x: torch.Tensor, g: torch.Tensor, taps, dst: torch.Tensor, sm: int, sk
     lib = L.lib()
     L.check(lib.ubr_wgrad_plan(C.byref(d), C.byref(nsplit), C.byref(nbytes)), "wgrad_plan")
     slabs = ws.get(nbytes.value, x.device)
+    if stream is not None:
+        # the workspace is grow-only: when a later call replaces it, the caching allocator must not recycle the old block
+        # for the compute stream while this (side-stream) launch still reads it
+        slabs.record_stream(stream)
     d.slabs = slabs.data_ptr()
     d.nsplit = nsplit.value
     st = L.stream_ptr() if stream is None else stream.cuda_stream
