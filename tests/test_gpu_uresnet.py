@@ -378,6 +378,32 @@ def test_bench_config_full_size_properties():
         assert torch.equal(g1, g2), "gradient of %s is not reproducible run to run" % n
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_two_stream_backward_equals_single_stream(dt, monkeypatch):
+    """The weight gradients run on a second HIP stream.  A FIRST backward of a fresh model (the slab workspace grows
+    and is replaced while earlier side-stream launches are still in flight) must give bitwise the gradients of the
+    single-stream schedule -- regression test for a recycled-workspace race that the full-size fixture test caught."""
+    sd = O.seeded_state_dict(O.uresnet_schema(3, 1, 16, 16), 42)
+    x, lab, wgt = synthetic.make_batch(2, 512, 512, 1000)
+    xt, lt, wt = torch.from_numpy(x).cuda(), torch.from_numpy(lab).cuda(), torch.from_numpy(wgt).cuda()
+    crit = PixelWiseNLLLoss()
+    res = {}
+    for mode in ("0", "1", "1"):
+        monkeypatch.setenv("UBR_WGRAD_STREAM", mode)
+        mm = _model(sd)
+        mm.train()
+        mm.compute_dtype = dt
+        crit(mm(xt), lt, wt).backward()
+        torch.cuda.synchronize()
+        g = [p.grad.clone() for p in mm.parameters()]
+        if mode in res:
+            for (n, _), a, b in zip(mm.named_parameters(), res[mode], g):
+                assert torch.equal(a, b), "two-stream gradient of %s differs run to run" % n
+        res[mode] = g
+    for (n, _), a, b in zip(mm.named_parameters(), res["0"], res["1"]):
+        assert torch.equal(a, b), "gradient of %s: two-stream schedule differs from the single-stream one" % n
+
+
 def test_errors_are_exceptions():
     m = UResNet(num_classes=3, input_channels=1, inplanes=16).cuda()
     with pytest.raises(RuntimeError):
