@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--model", default="uresnet", choices=["uresnet", "aspp"],
                     help="aspp = BASELINE configs[3]: ASPP_ResNet on 3-plane 512x832 input")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--optimizer", choices=["flat", "torch"], default="flat", help="flat: ubresnet_amd.optim.FlatAdam (one launch); torch: torch.optim.Adam(fused=True)")
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--breakdown-file", default="")
     return ap.parse_args()
@@ -137,10 +138,13 @@ def main():
     model.train()
     crit = PixelWiseNLLLoss()
     params = [p for p in model.parameters()]
-    try:
-        opt = torch.optim.Adam(params, lr=1e-5, weight_decay=1e-4, fused=True)   # reference: Adam(lr 1e-5, wd 1e-4), wlarcv2.py:155-157
-    except Exception:
-        opt = torch.optim.Adam(params, lr=1e-5, weight_decay=1e-4)
+    # reference: Adam(lr 1e-5, weight_decay 1e-4), wlarcv2.py:155-157.  Default: this package's flat Adam (same arithmetic, one
+    # launch over the flat parameter / gradient buffers); --optimizer torch uses torch.optim.Adam(fused=True).
+    if a.optimizer == "flat":
+        from ubresnet_amd.optim import FlatAdam
+        opt = FlatAdam(model, lr=1e-5, weight_decay=1e-4)
+    else:
+        opt = torch.optim.Adam(params, lr=1e-5, weight_decay=1e-4, fused=True)
     reducer = GradAllReducer(model) if dist.is_initialized() else None
 
     # synthetic crops: rank r holds images [r*b, (r+1)*b) of the global batch, resident in HBM
@@ -185,7 +189,8 @@ def main():
         "dtype": a.dtype, "data": "synthetic",
         "config": {"workload": "%s 3-class ip%d %s, batch %d per GPU (global %d), %dx%dx%d synthetic LArTPC crops, Adam(1e-5, wd 1e-4)"
                                % ("ub_uresnet" if a.model == "uresnet" else "ASPP_ResNet", a.inplanes, a.dtype, a.batch, gb, H, W, planes),
-                   "parallelism": "dp%d" % world, "global_batch": gb},
+                   "parallelism": "dp%d" % world, "global_batch": gb,
+                   "optimizer": "ubresnet_amd.optim.FlatAdam" if a.optimizer == "flat" else "torch.optim.Adam(fused=True)"},
         "final_loss": lossv,
     }
     esz = 4 if a.dtype == "f32" else 2

@@ -259,6 +259,20 @@ int ubr_cast_f64_to_f32(const double* src, int stride, int slots, float* dst, in
 int ubr_zero(void* p, int64_t bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Flat optimizer steps over one contiguous fp32 parameter buffer (laid out like the flat gradient
+ * buffer of the backward pass): ONE launch per step instead of one per tensor list.
+ * Formulas are torch.optim's (L2 weight decay added to the gradient, not decoupled):
+ *   Adam  (training/train_ubresnet2018_wlarcv2.py:155-157: lr 1e-5, weight_decay 1e-4)
+ *   SGD   (training/train_ubresnet2018_wlarcv1.py:127-129: momentum 0.9, weight_decay 1e-4)
+ * `step` is the 1-based step count (bias corrections); `grad_scale` multiplies the gradient first
+ * (1/world for a summed all-reduce, 1 otherwise); n must be a multiple of 4, buffers 16-byte aligned.
+ * ---------------------------------------------------------------------------------------- */
+int ubr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int64_t step, float grad_scale, void* stream);
+int ubr_sgd_step(float* param, const float* grad, float* momentum_buf /* NULL iff momentum == 0 */, int64_t n, float lr,
+                 float momentum, float dampening, float weight_decay, int nesterov, int first_step, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Whole-view tiling (deploy/run_ubresnet_wholeview.py:191-277 slices (bs,1,512,832) crops out of
  * [3,1,rows,cols] plane images and stitches the network output back).  tile_desc_host is an
  * int32 [ntiles][7] HOST array {plane, row0, col0, keep_r0, keep_r1, keep_c0, keep_c1}: the tile

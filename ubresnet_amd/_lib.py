@@ -87,7 +87,7 @@ SYMBOLS = [
     "ubr_block_tail_fwd", "ubr_block_tail_bwd_reduce", "ubr_block_tail_bwd_apply",
     "ubr_maxpool_fwd", "ubr_maxpool_bwd",
     "ubr_logsoftmax_bwd", "ubr_pixelwise_nll_fwd", "ubr_pixelwise_nll_bwd", "ubr_confusion",
-    "ubr_channel_sum", "ubr_cast_f64_to_f32", "ubr_zero", "ubr_crop_tiles", "ubr_stitch_tiles", "ubr_last_error", "ubr_version",
+    "ubr_channel_sum", "ubr_cast_f64_to_f32", "ubr_zero", "ubr_adam_step", "ubr_sgd_step", "ubr_crop_tiles", "ubr_stitch_tiles", "ubr_last_error", "ubr_version",
 ]
 
 _lib = None
@@ -132,6 +132,8 @@ def _declare(lib):
     lib.ubr_channel_sum.argtypes = [i32, i64, i32, vp, i64, vp, vp]
     lib.ubr_cast_f64_to_f32.argtypes = [vp, i32, i32, vp, i32, f64, i32, vp]
     lib.ubr_zero.argtypes = [vp, i64, vp]
+    lib.ubr_adam_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, f32, vp]
+    lib.ubr_sgd_step.argtypes = [vp, vp, vp, i64, f32, f32, f32, f32, i32, i32, f32, vp]
     lib.ubr_crop_tiles.argtypes = [vp, i32, i32, i32, C.POINTER(C.c_int32), i32, i32, i32, vp, vp]
     lib.ubr_stitch_tiles.argtypes = [vp, i32, i32, i32, C.POINTER(C.c_int32), i32, vp, i32, i32, i32, vp]
     for name in SYMBOLS:

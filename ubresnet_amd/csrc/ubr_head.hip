@@ -3,6 +3,7 @@
 // re-layout (models/ub_uresnet.py:143), PixelWiseNLLLoss forward/backward
 // (training/pixelwise_nllloss.py:41-61) and the one-pass confusion matrix behind accuracy()
 // (training/train_ubresnet2018_wlarcv2.py:509-566).
+#include <math.h>
 #include "ubr_common.h"
 #include "ubr_host.h"
 #ifndef UBR_MAX_TILES
@@ -495,6 +496,80 @@ extern "C" int ubr_stitch_tiles(const float* scores, int C, int th, int tw, cons
   if (rc != UBR_OK) return rc;
   hipLaunchKernelGGL(stitch_tiles_kernel, dim3(ubr_cdiv(C * th * tw, 256 * 8), ntiles), dim3(256), 0, (hipStream_t)stream, scores, out, k);
   UBR_LAUNCH_CHECK("ubr_stitch_tiles");
+  return UBR_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Flat optimizers: every parameter of the network lives in one fp32 buffer laid out like the flat gradient buffer
+// the backward pass fills, so a whole optimizer step is ONE streaming kernel (reference: torch.optim.Adam(lr 1e-5,
+// weight_decay 1e-4), training/train_ubresnet2018_wlarcv2.py:155-157; SGD momentum 0.9, train_ubresnet2018_wlarcv1.py:127-129).
+// Arithmetic follows torch.optim's single-tensor formulas in fp32 (L2 weight decay added to the gradient).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long n4, float lr, float b1, float b2, float eps, float wd,
+                                                   float bc1, float sqrt_bc2, float gscale) {
+  const float step_size = lr / bc1;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    float4 P = reinterpret_cast<float4*>(p)[i], G = reinterpret_cast<const float4*>(g)[i];
+    float4 M = reinterpret_cast<float4*>(m)[i], V = reinterpret_cast<float4*>(v)[i];
+    float pp[4] = {P.x, P.y, P.z, P.w}, gg[4] = {G.x, G.y, G.z, G.w}, mm[4] = {M.x, M.y, M.z, M.w}, vv[4] = {V.x, V.y, V.z, V.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float gr = gg[e] * gscale;
+      gr = fmaf(wd, pp[e], gr);                                  // grad.add(param, alpha=weight_decay)
+      mm[e] = mm[e] + (1.f - b1) * (gr - mm[e]);                 // exp_avg.lerp_(grad, 1 - beta1)
+      vv[e] = b2 * vv[e] + (1.f - b2) * gr * gr;                 // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+      const float denom = sqrtf(vv[e]) / sqrt_bc2 + eps;
+      pp[e] = pp[e] - step_size * (mm[e] / denom);               // param.addcdiv_(exp_avg, denom, value=-step_size)
+    }
+    reinterpret_cast<float4*>(p)[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+    reinterpret_cast<float4*>(m)[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+    reinterpret_cast<float4*>(v)[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+  }
+}
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, long n4,
+                                                  float lr, float momentum, float dampening, float wd, int nesterov, int first,
+                                                  float gscale) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    float4 P = reinterpret_cast<float4*>(p)[i], G = reinterpret_cast<const float4*>(g)[i];
+    float4 B = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (buf != nullptr && !first) B = reinterpret_cast<float4*>(buf)[i];
+    float pp[4] = {P.x, P.y, P.z, P.w}, gg[4] = {G.x, G.y, G.z, G.w}, bb[4] = {B.x, B.y, B.z, B.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float gr = fmaf(wd, pp[e], gg[e] * gscale);
+      if (buf != nullptr) {
+        bb[e] = first ? gr : momentum * bb[e] + (1.f - dampening) * gr;   // torch.optim.SGD: first step clones the gradient
+        gr = nesterov ? fmaf(momentum, bb[e], gr) : bb[e];
+      }
+      pp[e] = pp[e] - lr * gr;
+    }
+    reinterpret_cast<float4*>(p)[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+    if (buf != nullptr) reinterpret_cast<float4*>(buf)[i] = make_float4(bb[0], bb[1], bb[2], bb[3]);
+  }
+}
+static int opt_blocks(long n4) {
+  long b = (n4 + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+extern "C" int ubr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, int64_t step, float grad_scale, void* stream) {
+  UBR_CHECK(param && grad && exp_avg && exp_avg_sq && n > 0 && n % 4 == 0 && step >= 1, "ubr_adam_step: bad arguments (n must be a multiple of 4)");
+  UBR_CHECK(ubr_aligned16(param) && ubr_aligned16(grad) && ubr_aligned16(exp_avg) && ubr_aligned16(exp_avg_sq), "ubr_adam_step: buffers must be 16-byte aligned");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adam_kernel, dim3(opt_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, (long)(n / 4),
+                     lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
+  UBR_LAUNCH_CHECK("ubr_adam_step");
+  return UBR_OK;
+}
+extern "C" int ubr_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum, float dampening,
+                            float weight_decay, int nesterov, int first_step, float grad_scale, void* stream) {
+  UBR_CHECK(param && grad && n > 0 && n % 4 == 0, "ubr_sgd_step: bad arguments (n must be a multiple of 4)");
+  UBR_CHECK((momentum == 0.f) == (momentum_buf == nullptr), "ubr_sgd_step: momentum buffer iff momentum != 0");
+  UBR_CHECK(ubr_aligned16(param) && ubr_aligned16(grad) && (!momentum_buf || ubr_aligned16(momentum_buf)), "ubr_sgd_step: buffers must be 16-byte aligned");
+  hipLaunchKernelGGL(sgd_kernel, dim3(opt_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, param, grad, momentum_buf, (long)(n / 4), lr, momentum,
+                     dampening, weight_decay, nesterov, first_step, grad_scale);
+  UBR_LAUNCH_CHECK("ubr_sgd_step");
   return UBR_OK;
 }
 

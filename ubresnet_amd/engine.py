@@ -524,7 +524,10 @@ class Engine:
         views = {}
         for name, p in self.grad_order:
             o = self.grad_offsets[name]
-            views[id(p)] = flat[o:o + p.numel()].view(p.shape)
+            n = p.numel()
+            views[id(p)] = flat[o:o + n].view(p.shape)
+            if n % 4:       # padding up to the next 16-byte boundary (conv11.bias of a 3-class net): defined, for flat optimizers
+                flat[o + n:o + (n + 3) // 4 * 4].zero_()
         return flat, views
 
     def _stage_notifier(self, flat, grad_ready):
