@@ -162,12 +162,15 @@ class DeviceStager(object):
                       torch.empty((b, h, w), dtype=torch.float32).pin_memory()) for _ in range(2)]
         self._slot = 0
         self._inflight = None
+        self._copied = [None, None]          # per pinned slot: event after its last host->device copy
         self._prefetch()
 
     def _prefetch(self):
         torch = self.torch
         b, p, h, w = self.shape
         data = self.loader[0]
+        if self._copied[self._slot] is not None:
+            self._copied[self._slot].synchronize()      # the async copy that last read this pinned slot must be done before the host refills it
         src, lab, wgt = self._pin[self._slot]
         src.copy_(torch.from_numpy(data["source_%s" % self.tag].reshape((b, p, h, w))))
         lab.copy_(torch.from_numpy(data["label_%s" % self.tag].reshape((b, h, w))))        # float32 -> int64
@@ -181,6 +184,7 @@ class DeviceStager(object):
             ev = torch.cuda.Event()
             ev.record(self.stream)
         self._inflight = (dev, ev)
+        self._copied[self._slot] = ev
         self._slot ^= 1
 
     def next(self):
