@@ -91,6 +91,30 @@ def cpu_baseline(size, inplanes, seconds_budget=20.0):
             p[k] = v
         return float(loss.detach())
 
+    # BASELINE's second metric: per-class pixel IoU of this build's class map against the CPU reference path, same
+    # weights, same batch, train-mode forward (batch statistics), before any update
+    iou = None
+    try:
+        from ubresnet_amd.models.ub_uresnet import UResNet
+        with torch.no_grad():
+            ref = O.uresnet_forward(p, xt, True, {})
+            m = UResNet(num_classes=3, input_channels=1, inplanes=inplanes)
+            m.load_state_dict(sd)
+            m = m.cuda().train()
+            a = ref.argmax(1).reshape(-1)
+            top2 = torch.topk(ref, 2, dim=1)[0]
+            safe = ((top2[:, 0] - top2[:, 1]) > 0.2).reshape(-1)
+            iou = {"pixels": int(a.numel()), "margin_gt_0.2_fraction": float(safe.float().mean())}
+            for name, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+                m.compute_dtype = dt
+                b = m(xt.cuda()).argmax(1).reshape(-1).cpu()
+                for tag, sel in (("", slice(None)), ("_margin_gt_0.2", safe)):
+                    cm = torch.bincount(a[sel] * 3 + b[sel], minlength=9).reshape(3, 3)
+                    iou[name + tag] = [float(v) for v in O.iou_from_confusion(cm)]
+            del m
+    except Exception as e:     # the IoU report must never take the benchmark line down
+        iou = {"error": repr(e)}
+
     tw = time.time()
     step()
     tw = time.time() - tw
@@ -103,7 +127,7 @@ def cpu_baseline(size, inplanes, seconds_budget=20.0):
     el = time.time() - t0
     return {"value": B * n / el, "unit": "images/sec", "cores": cores, "kind": "port",
             "sample": "%d timed train steps (1 warm-up) of the CPU oracle, UResNet ip%d fp32, batch %d, %dx%d, Adam" % (n, inplanes, B, size, size),
-            "ms_per_step": 1e3 * el / n}
+            "ms_per_step": 1e3 * el / n, "iou_vs_reference": iou}
 
 
 def main():
