@@ -470,6 +470,11 @@ static bool plan_for(const ubr_conv_desc* d, int cfg, int dymin, int dymax, int 
   const int cpu = ubr_cpu(d->dtype);
   const int CU = d->Cin / cpu;
   int UPB = (CU % 4 == 0) ? 4 : (CU % 2 == 0 ? 2 : 1);
+  // Stride-2 convs (halo of 4x the output pixels) and 16-tap layers (the data gradients of the transposed convs: a
+  // 65 KB weight slab per 4-unit cin block) overflow 80 KB of LDS with 4-unit blocks and run one workgroup per CU;
+  // 2-unit blocks halve both images.  The rule depends on the LAYER only (never on the tile or the batch), so an
+  // image's result does not depend on what it is batched with.
+  if (UPB == 4 && (d->S == 2 || d->ntaps >= 16)) UPB = 2;
   const int nunits = d->ntaps * UPB;
   const int steps = (nunits + 3) / 4;
   const int HH = (TH - 1) * d->S + 1 + (dymax - dymin);
