@@ -594,6 +594,12 @@ extern "C" int ubr_conv(const ubr_conv_desc* d, void* stream) {
   g_last_conv_cfg[0] = c.FW; g_last_conv_cfg[1] = c.NT; g_last_conv_cfg[2] = c.TWF;
   dim3 grid((unsigned)(best.tiles_x * best.tiles_y * d->N), (unsigned)(d->Cout_pad / (c.NT * 16)));
   hipStream_t st = (hipStream_t)stream;
+  {
+    static const bool dbg = [] { const char* e = getenv("UBR_CONV_DEBUG"); return e && atoi(e) != 0; }();
+    if (dbg)
+      fprintf(stderr, "ubr_conv plan: N%d %dx%d Cin%d Cout%d taps%d S%d | cfg%d (%d,%d,%d) UPB%d nblk%d lds %zu wgs %u x %u\n", d->N, d->OH, d->OW,
+              d->Cin, d->Cout, d->ntaps, d->S, best.cfg, c.FW, c.NT, c.TWF, best.UPB, k.nblk, best.lds, grid.x, grid.y);
+  }
   switch (d->dtype) {
     case UBR_F32: return launch_T<float>(best.cfg, k, grid, best.lds, st);
     case UBR_BF16: return launch_T<bf16_t>(best.cfg, k, grid, best.lds, st);
