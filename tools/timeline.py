@@ -3,7 +3,7 @@ f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Stream_Id", r.get("Queue_Id", "0"))) for r in rows)
 # find step boundaries: multi_tensor_apply (Adam) kernels mark step ends
-adam = [i for i, e in enumerate(ev) if "FusedOptimizer" in e[2] or "multi_tensor_apply" in e[2]]
+adam = [i for i, e in enumerate(ev) if "FusedOptimizer" in e[2] or "multi_tensor_apply" in e[2] or "adam_kernel" in e[2] or "sgd_kernel" in e[2]]
 # group consecutive adam kernels
 ends = []
 for i in adam:
