@@ -152,3 +152,17 @@ def test_shard_range():
     assert [shard_range(128, r, 8) for r in (0, 7)] == [(0, 16), (112, 128)]
     with pytest.raises(ValueError):
         shard_range(10, 0, 4)
+
+
+def test_header_is_plain_c(tmp_path):
+    """the drop-in boundary is a C ABI: include/ubresnet_hip.h must compile as C99 with nothing but <stdint.h>"""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "ubresnet_hip.h")
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "%s"\nint main(void) { ubr_conv_desc d; (void)d; return (int)sizeof(ubr_wgrad_desc) * 0; }\n' % hdr)
+    r = subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-fsyntax-only", str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
