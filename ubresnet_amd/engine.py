@@ -61,6 +61,7 @@ class Engine:
         self._side_on = False
         self._evs, self._ev_next, self._main = [], 0, None
         self._red_buf, self._red_off, self._red_elems = None, 0, 0
+        self._bwd_packed, self._pack_evs = None, None
         self.bn_sites: List[BNSite] = []
         self._bn_of: Dict[int, BNSite] = {}
         for m in model.modules():
@@ -156,12 +157,38 @@ class Engine:
         self._plans[key] = plan
         return plan
 
-    def pack_all(self, dt, device, group):
+    def pack_all(self, dt, device, group, stream=None):
         plan = self._pack_plan(dt, device)
         if plan["counts"][group]:
-            L.check(L.lib().ubr_pack_weights_batched(L.dtype_id(dt), plan[group].data_ptr(), plan["counts"][group], L.stream_ptr()),
+            st = L.stream_ptr() if stream is None else stream.cuda_stream
+            L.check(L.lib().ubr_pack_weights_batched(L.dtype_id(dt), plan[group].data_ptr(), plan["counts"][group], st),
                     "pack_weights_batched")
         self._images = plan["images"]
+
+    def _pack_bwd_early(self, dt, dev):
+        """Training forward: the backward-orientation weight images are not needed before backward starts, so their
+        repack runs on the side stream under the forward pass instead of at the head of the backward chain."""
+        import os
+        self._bwd_packed = None
+        if dev.type != "cuda" or os.environ.get("UBR_WGRAD_STREAM", "1") == "0":
+            return
+        self._ensure_side(dev)
+        if self._pack_evs is None:
+            self._pack_evs = (torch.cuda.Event(), torch.cuda.Event())
+        e0, e1 = self._pack_evs
+        e0.record(torch.cuda.current_stream(dev))      # weights are final and every earlier reader of the images is queued
+        self.side.wait_event(e0)
+        self.pack_all(dt, dev, "bwd", stream=self.side)
+        e1.record(self.side)
+        self._bwd_packed = (dt, dev)
+
+    def _pack_bwd(self, dt, dev):
+        if self._bwd_packed == (dt, dev):
+            torch.cuda.current_stream(dev).wait_event(self._pack_evs[1])
+            self._bwd_packed = None
+            self._images = self._pack_plan(dt, dev)["images"]
+        else:
+            self.pack_all(dt, dev, "bwd")
 
     def packed(self, param: torch.Tensor, dtype, orient: str) -> torch.Tensor:
         """packed image of a weight for this pass (written by pack_all)"""
@@ -272,18 +299,24 @@ class Engine:
         rocprofv3 sees them)."""
         import os
         self._side_on = dev.type == "cuda" and os.environ.get("UBR_WGRAD_STREAM", "1") != "0"
-        if self._side_on and self.side is None:
-            # HIP maps normal-priority streams round-robin onto a few hardware queues; once RCCL has created its own
-            # streams the side stream can land on the compute stream's queue and the two serialise (measured under
-            # torchrun: 17.7 instead of 15.1 ms/step).  High-priority streams use separate queues, so in a
-            # process-group job the side stream is created with high priority (costs 0.2 ms/step standalone).
-            import torch.distributed as _dist
-            in_job = _dist.is_available() and _dist.is_initialized()
-            prio = int(os.environ.get("UBR_SIDE_PRIORITY", "-1" if in_job else "0"))
-            self.side = torch.cuda.Stream(device=dev, priority=prio)
+        if self._side_on:
+            self._ensure_side(dev)
         if self._side_on:
             self._main = torch.cuda.current_stream(dev)
             self._ev_next = 0
+
+    def _ensure_side(self, dev):
+        if self.side is not None:
+            return
+        import os
+        # HIP maps normal-priority streams round-robin onto a few hardware queues; once RCCL has created its own
+        # streams the side stream can land on the compute stream's queue and the two serialise (measured under
+        # torchrun: 17.7 instead of 15.1 ms/step).  High-priority streams use separate queues, so in a
+        # process-group job the side stream is created with high priority (costs 0.2 ms/step standalone).
+        import torch.distributed as _dist
+        in_job = _dist.is_available() and _dist.is_initialized()
+        prio = int(os.environ.get("UBR_SIDE_PRIORITY", "-1" if in_job else "0"))
+        self.side = torch.cuda.Stream(device=dev, priority=prio)
 
     def _side_end(self, dev):
         if self._side_on:
@@ -645,6 +678,8 @@ class Engine:
         sv = Saved()
         self._alloc_pass_workspaces(sv, dev, training)
         self.pack_all(dt, dev, "fwd")
+        if save:
+            self._pack_bwd_early(dt, dev)
         E = lambda *shape: torch.empty(shape, dtype=dt, device=dev)
         C3, C4, C5 = 8 * ip, 16 * ip, 32 * ip
         # affine arena: [acat3 | acat4 | acat5 | cat4 (up,post3,e3) | cat5 (up,post4,e4) | skip5 (post5,e5)]
@@ -712,7 +747,7 @@ class Engine:
         m = self.model
         dt, dev = sv.dt, sv.x.device
         self._rebind(sv)
-        self.pack_all(dt, dev, "bwd")
+        self._pack_bwd(dt, dev)
         flat, views = self._grad_views(dev)
         G = lambda p: views[id(p)]
         stage_done = self._stage_notifier(flat, grad_ready)
@@ -774,6 +809,8 @@ class Engine:
         sv = Saved()
         self._alloc_pass_workspaces(sv, dev, training)
         self.pack_all(dt, dev, "fwd")
+        if save:
+            self._pack_bwd_early(dt, dev)
         E = lambda *shape: torch.empty(shape, dtype=dt, device=dev)
 
         # stem: conv1 -> (bn1 + relu folded into consumers) -> pool ; x0 goes into dec1's concat buffer
@@ -835,7 +872,7 @@ class Engine:
         dt = sv.dt
         dev = sv.x.device
         self._rebind(sv)
-        self.pack_all(dt, dev, "bwd")
+        self._pack_bwd(dt, dev)
         flat, views = self._grad_views(dev)
         G = lambda p: views[id(p)]
         stage_done = self._stage_notifier(flat, grad_ready)
