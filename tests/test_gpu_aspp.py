@@ -74,3 +74,32 @@ def test_aspp_bf16_runs(golden_dir):
     agree = float((ref.argmax(1) == out.argmax(1)).float().mean())
     print("aspp bf16 pixel agreement", agree)
     assert agree >= 0.97
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_aspp_two_stream_backward_equals_single_stream(dt, monkeypatch):
+    """BASELINE config 4's shape per rank (3x512x832, batch 2): the first backward of a fresh ASPP-ResNet on the
+    two-stream schedule gives bitwise the single-stream gradients, run to run (dilated / wide-slot weight-gradient
+    variants, the affine arena and the stride-1 pools included)."""
+    sd = O.seeded_state_dict(O.aspp_resnet_schema(3, 3, 16), 42)
+    x, lab, wgt = synthetic.make_batch(2, 512, 832, 1000, planes=3)
+    xt, lt, wt = torch.from_numpy(x).cuda(), torch.from_numpy(lab).cuda(), torch.from_numpy(wgt).cuda()
+    crit = PixelWiseNLLLoss()
+    res = {}
+    for mode in ("0", "1", "1"):
+        monkeypatch.setenv("UBR_WGRAD_STREAM", mode)
+        mm = ASPP_ResNet(num_classes=3, in_channels=3, inplanes=16, showsizes=False)
+        mm.load_state_dict(sd)
+        mm = mm.cuda().train()
+        mm.compute_dtype = dt
+        crit(mm(xt), lt, wt).backward()
+        torch.cuda.synchronize()
+        g = [p.grad.clone() for p in mm.parameters()]
+        for n_, t in zip([n for n, _ in mm.named_parameters()], g):
+            assert torch.isfinite(t).all(), n_
+        if mode in res:
+            for (n, _), a, b in zip(mm.named_parameters(), res[mode], g):
+                assert torch.equal(a, b), "two-stream gradient of %s differs run to run" % n
+        res[mode] = g
+    for (n, _), a, b in zip(mm.named_parameters(), res["0"], res["1"]):
+        assert torch.equal(a, b), "gradient of %s: two-stream schedule differs from the single-stream one" % n
