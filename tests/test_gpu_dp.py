@@ -52,6 +52,8 @@ def _worker(rank, world, port, q):
     m = UResNet(3, 1, 16)
     m.load_state_dict(sd)
     m = m.cuda().train()
+    from ubresnet_amd.optim import FlatAdam
+    opt = FlatAdam(m, lr=1e-3, weight_decay=1e-4)      # parameters become views of one buffer before the first forward
     red = GradAllReducer(m, bucket_bytes=8 << 20)
     loss = crit(m(torch.from_numpy(x[lo:hi]).cuda()), torch.from_numpy(lab[lo:hi]).cuda(), torch.from_numpy(wgt[lo:hi]).cuda())
     loss.backward()
@@ -66,7 +68,13 @@ def _worker(rank, world, port, q):
         worst = max(worst, err)
         inside = flat.data_ptr() <= p.grad.data_ptr() < flat.data_ptr() + flat.numel() * 4
         ok = ok and inside and (err <= 1e-5 or want.abs().max().item() < 1e-6)
-    q.put((rank, bool(ok), worst))
+    # the replicas take the same optimizer step from the averaged flat buffer and stay bitwise in sync
+    before = opt.flat.clone()
+    opt.step()
+    torch.cuda.synchronize()
+    moved = float((opt.flat - before).abs().max())
+    digest = opt.flat.double().sum().item()
+    q.put((rank, bool(ok and moved > 0 and torch.isfinite(opt.flat).all().item()), worst, digest))
     dist.destroy_process_group()
 
 
@@ -82,6 +90,7 @@ def test_two_rank_gradient_average():
         p.join(timeout=60)
     print("dp worst rel err per rank", [r[2] for r in res])
     assert [r[:2] for r in res] == [(0, True), (1, True)]
+    assert res[0][3] == res[1][3], "replicas diverged after the optimizer step: %r vs %r" % (res[0][3], res[1][3])
 
 
 def test_grad_accumulates_like_autograd():
