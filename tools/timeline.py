@@ -43,3 +43,19 @@ for s, e, n, q in step:
     fam[(q, key)] += (e - s) / 1e6
 for (q, key), v in sorted(fam.items(), key=lambda kv: -kv[1])[:40]:
     print("stream %s  %-62s %.3f ms" % (q, key, v))
+# tail of the backward pass: after the compute stream's last kernel, how long until the optimizer can start (side stream catching up)
+opt_i = [i for i, e in enumerate(step) if "adam_kernel" in e[2] or "sgd_kernel" in e[2] or "FusedOptimizer" in e[2]]
+if opt_i:
+    o = opt_i[0]
+    main_q = step[o][3]
+    prev_main = [e for e in step[:o] if e[3] == main_q]
+    prev_side = [e for e in step[:o] if e[3] != main_q]
+    if prev_main and prev_side:
+        t_main = max(e[1] for e in prev_main); t_side = max(e[1] for e in prev_side)
+        print("backward tail: compute stream done %.3f ms before the optimizer starts; side stream done %.3f ms before; side lags the compute stream by %.3f ms"
+              % ((step[o][0] - t_main) / 1e6, (step[o][0] - t_side) / 1e6, (t_side - t_main) / 1e6))
+        # last few side kernels
+        tail = sorted(prev_side, key=lambda e: e[1])[-6:]
+        for s_, e_, n_, q_ in tail:
+            print("   side tail kernel %-60s start %+8.1f us end %+8.1f us (relative to the compute stream's last kernel end)"
+                  % (n_.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:60], (s_ - t_main) / 1e3, (e_ - t_main) / 1e3))
