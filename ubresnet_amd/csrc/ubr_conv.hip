@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256, ((NT == 4 && FW <= 2 && !PIPE) ? 4 : 2)) void 
     // Item i = tid + 256 m maps to halo pixel i >> lgUPB (LDS is linear in i); its (row, column) and global
     // byte offset advance by constant steps with one conditional wrap -- no division or 64-bit multiply per item.
     {
-      constexpr int SB = 4;
+      constexpr int SB = (NT <= 2 && TWF == 2) ? 6 : 4;   // thin tiles: the whole halo (<= 5.3 items per thread for 3x3) in ONE batch -- bytes in flight, not instructions, limit this phase
       const int c = tid & (k.UPB - 1);
       const int ch0 = (blk * k.UPB + c) * CPU;
       float xsub[CPU], xsc[CPU], xsh[CPU], xlo[CPU];
