@@ -240,10 +240,12 @@ int ubr_maxpool_bwd(int dtype, int N, int H, int W, int C, int stride, const voi
 int ubr_logsoftmax_bwd(int dtype, int N, int C, int H, int W, const float* g_logp_nchw, const float* logp_nchw,
                        void* g_logits, int64_t gl_ps, void* stream);
 /* PixelWiseNLLLoss.forward (training/pixelwise_nllloss.py:41-61): acc[0] += sum over pixels of
- * -predict[b,target,h,w]*classw[target]*pixelweights ; loss = acc/(B*H*W) is formed by the caller. */
+ * -predict[b,target,h,w]*classw[target]*pixelweights ; loss = acc/(B*H*W) is formed by the caller.
+ * bad_labels (optional device counter, caller-zeroed): += number of targets outside [0,C) that are not ignore_index;
+ * F.nll_loss raises a device assert for those, the host side of this package raises RuntimeError from the count. */
 int ubr_pixelwise_nll_fwd(const float* predict_nchw, const int64_t* target, const float* pixelweights,
                           const float* classw /*NULL*/, int N, int C, int H, int W, int64_t ignore_index,
-                          double* acc, void* stream);
+                          double* acc, unsigned long long* bad_labels /*NULL*/, void* stream);
 int ubr_pixelwise_nll_bwd(const float* g_loss /*device scalar*/, const int64_t* target, const float* pixelweights,
                           const float* classw, int N, int C, int H, int W, int64_t ignore_index,
                           float* g_predict_nchw, void* stream);

@@ -45,6 +45,25 @@ def _worker(rank, world, port, q):
     ok = ok and torch.allclose(flat2, torch.full((n,), sum(range(1, world + 1)) / world))
     lo, hi = shard_range(8, rank, world)
     ok = ok and (hi - lo) == 4 and lo == rank * 4
+    # construction broadcasts rank 0's parameters and buffers (replicas need not share a seed)
+    torch.manual_seed(100 + rank)
+    net = torch.nn.Sequential(torch.nn.Conv2d(2, 3, 3), torch.nn.BatchNorm2d(3))
+    net[1].running_mean.add_(float(rank))
+    red2 = GradAllReducer(net)
+    digest = torch.cat([t.detach().reshape(-1).double() for t in list(net.parameters()) + list(net.buffers())])
+    gathered = [torch.zeros_like(digest) for _ in range(world)]
+    dist.all_gather(gathered, digest)
+    ok = ok and all(torch.equal(gathered[0], t) for t in gathered) and float(net[1].running_mean.abs().max()) == 0.0
+    # accumulated passes: .grad tensors that already exist are reduced by finish(), not the in-flight flat buffer
+    for p in net.parameters():
+        p.grad = torch.full_like(p, float(rank + 1))
+    net._grad_accum_pending()
+    red2.finish()
+    ok = ok and all(torch.allclose(p.grad, torch.full_like(p, sum(range(1, world + 1)) / world)) for p in net.parameters())
+    # optional rank-independent BatchNorm statistics for checkpoints
+    net[1].running_var.fill_(float(rank))
+    red2.average_bn_stats()
+    ok = ok and torch.allclose(net[1].running_var, torch.full((3,), (world - 1) / 2.0))
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 

@@ -166,3 +166,53 @@ def test_header_is_plain_c(tmp_path):
     src.write_text('#include "%s"\nint main(void) { ubr_conv_desc d; (void)d; return (int)sizeof(ubr_wgrad_desc) * 0; }\n' % hdr)
     r = subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-fsyntax-only", str(src)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_aspp_resnet1_alias_both_import_styles():
+    """the reference's ASPP train scripts import `ASPP_ResNet1` (training/Sem_Seg_ASPP_ResNet1.py:43,
+    training/grid_scripts/train_aspp_wlarcv1_tuftsgrid.py:38): both styles resolve to the one module"""
+    import subprocess, sys
+    code = ("import sys; sys.path.append(%r); sys.path.append(%r); from ASPP_ResNet1 import ASPP_ResNet; "
+            "from models.ASPP_ResNet1 import ASPP_ResNet as B; from ubresnet_amd.models.ASPP_ResNet1 import ASPP_ResNet as C; "
+            "from ubresnet_amd.models.ASPP_ResNet import ASPP_ResNet as D; assert ASPP_ResNet is B is C is D; "
+            "m = ASPP_ResNet(3, 3, 16, False); print('ok', len(m.state_dict()))"
+            % (os.path.join(REPO, "ubresnet_amd", "models"), os.path.join(REPO, "ubresnet_amd")))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd="/tmp")
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr
+
+
+def test_data_parallel_wrappers_raise_instead_of_training_on_nothing():
+    """nn.DataParallel replicas hold non-leaf broadcast copies of the parameters and DDP relies on AccumulateGrad hooks;
+    the fused autograd node would feed neither, so both must raise (SURVEY.md section 8b: errors must raise;
+    reference wrap: training/train_ubresnet2018_wlarcv2.py:99,103)."""
+    from ubresnet_amd.models.ub_uresnet import UResNet
+    m = UResNet(num_classes=3, input_channels=1, inplanes=16)
+    x = torch.zeros(1, 1, 32, 32)
+    # what torch.nn.parallel.replicate does to a replica: parameters become plain non-leaf tensors
+    reps = {id(mod): mod._replicate_for_data_parallel() for mod in m.modules()}
+    for mod in m.modules():
+        r = reps[id(mod)]
+        for name, child in mod._modules.items():
+            if child is not None:
+                r._modules[name] = reps[id(child)]
+        for name, p in mod._parameters.items():
+            if p is not None:
+                r._parameters[name] = p * 1.0            # non-leaf, requires_grad (stands in for Broadcast.apply output)
+    replica = reps[id(m)]
+    assert not replica.conv11.weight.is_leaf
+    with pytest.raises(RuntimeError, match="GradAllReducer"):
+        replica(x)
+    # DistributedDataParallel marks its forward through a class attribute
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    old = DDP._active_ddp_module
+    DDP._active_ddp_module = object()
+    try:
+        with pytest.raises(RuntimeError, match="DistributedDataParallel"):
+            m(x)
+    finally:
+        DDP._active_ddp_module = old
+    with pytest.raises(RuntimeError, match="input requires grad"):
+        m(x.clone().requires_grad_(True))
+    # forward-only use is unaffected by the checks (it still refuses CPU tensors)
+    with torch.no_grad(), pytest.raises(RuntimeError, match="ROCm device"):
+        m(x)

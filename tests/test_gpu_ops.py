@@ -478,3 +478,33 @@ def test_pixelwise_nll_and_confusion():
     assert torch.equal(cm, O.confusion_matrix(lp, tg2))
     acc, racc = metrics.accuracy(lp.to(DEV), tg2.to(DEV)), O.accuracy(lp, tg2)
     assert all(abs(a - b) < 1e-9 for a, b in zip(acc, racc))
+
+
+def test_out_of_range_labels_raise():
+    """F.nll_loss device-asserts on a target outside [0,C) other than ignore_index (training/pixelwise_nllloss.py:51); the
+    HIP loss counts them and raises RuntimeError -- at the next loss call by default (asynchronous, no sync in the step)"""
+    from ubresnet_amd.training import pixelwise_nllloss as PL
+    lp = torch.log_softmax(torch.randn(2, 3, 8, 8, device="cuda"), 1)
+    tg = torch.randint(0, 3, (2, 8, 8), device="cuda")
+    pw = torch.ones(2, 8, 8, device="cuda")
+    crit = PL.PixelWiseNLLLoss()
+    good = crit(lp, tg, pw)
+    tg_ign = tg.clone(); tg_ign[0, 0, :4] = -100          # ignore_index is not an error
+    crit(lp, tg_ign, pw)
+    torch.cuda.synchronize()
+    crit(lp, tg, pw)                                       # polls the two finished checks: clean
+    bad = tg.clone(); bad[1, 2, 3] = 3                     # the 4-class cosmic labels fed to a 3-class network
+    loss = crit(lp, bad, pw)                               # value is defined (pixel contributes 0), the report is pending
+    assert torch.isfinite(loss)
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="outside"):
+        crit(lp, tg, pw)
+    old = PL._label_check.mode
+    PL._label_check.mode = "sync"
+    try:
+        with pytest.raises(RuntimeError, match="outside"):
+            crit(lp, bad, pw)
+    finally:
+        PL._label_check.mode = old
+        PL._label_check.pending.clear()
+    assert abs(float(crit(lp, tg, pw)) - float(good)) < 1e-7

@@ -126,3 +126,20 @@ def test_flat_adam_gathers_when_grads_are_not_the_flat_views():
     torch.cuda.synchronize()
     worst = max(_maxrel(p.detach(), q.detach()) for p, q in zip(ma.parameters(), mb.parameters()))
     assert worst <= 2e-5, worst
+
+
+def test_step_without_gradients_changes_nothing():
+    """torch.optim skips parameters that have no gradient: a step() with no backward before it must not decay weights or
+    advance the moments (and a partially frozen model is refused, the flat kernel cannot skip ranges)"""
+    ma, _ = _pair()
+    for opt in (FlatAdam(ma, lr=1e-2, weight_decay=1e-1), FlatSGD(ma, lr=1e-2, momentum=0.9, weight_decay=1e-1)):
+        before = opt.flat.clone()
+        opt.zero_grad()
+        opt.step()
+        torch.cuda.synchronize()
+        assert opt.steps == 0 and torch.equal(opt.flat, before)
+    x, lab, wgt = _batch(0)
+    PixelWiseNLLLoss()(ma(x), lab, wgt).backward()
+    ma.conv11.bias.grad = None
+    with pytest.raises(RuntimeError, match="no gradient"):
+        opt.step()

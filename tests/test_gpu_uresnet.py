@@ -70,6 +70,9 @@ def test_train_step_matches_reference_fixture_and_oracle(golden_dir, tag):
     ref_out = torch.from_numpy(g["logp_train"])
     e = _rel(out.detach().cpu(), ref_out)
     assert e <= 1e-3, "train log-probs rel err %.3e" % e
+    # per-element bar (train-mode log-probabilities are O(10), so this is the meaningful form of "1e-3 relative")
+    d = (out.detach().cpu() - ref_out).abs()
+    assert bool((d <= 1e-3 * ref_out.abs() + 1e-4).all()), "train log-probs: worst per-element excess %.3e" % float((d - 1e-3 * ref_out.abs()).max())
     assert abs(loss.item() - float(g["loss"])) <= 1e-4 * abs(float(g["loss"]))
     # running statistics follow nn.BatchNorm2d (momentum 0.1, unbiased variance)
     after = m.state_dict()
@@ -122,15 +125,15 @@ def _grad_row(n, gv, g32, g64):
     return (n, emax, fmax, el2, fl2, cos)
 
 
-def _grad_verdict(row):
+def _grad_verdict(row, cos_min=0.9999, l2_max=2e-2):
     """A gradient passes if it is as close to the fp64 truth as PyTorch-CPU fp32 is (10x its floor + 5e-4),
     or -- when a ReLU mask flipped somewhere (a legitimate fp32 outcome, see the docstring above) -- if it
-    still points the same way: cosine >= 0.995 and relative L2 error <= 0.1.  Wiring or indexing bugs give
-    O(1) errors and fail both."""
+    still points the same way: cosine >= 0.9999 and relative L2 error <= 2e-2 (the measured envelope is
+    L2 <= 1e-2, cosine >= 0.99996).  Wiring or indexing bugs give O(1) errors and fail both."""
     n, emax, fmax, el2, fl2, cos = row
     if emax <= 10 * fmax + 5e-4:
         return []
-    if cos >= 0.995 and el2 <= 0.1:
+    if cos >= cos_min and el2 <= l2_max:
         return []
     return ["grad %s: max-rel %.3e (fp32 floor %.3e), l2-rel %.3e, cos %.5f" % (n, emax, fmax, el2, cos)]
 

@@ -126,7 +126,7 @@ def _declare(lib):
     lib.ubr_maxpool_fwd.argtypes = [i32, i32, i32, i32, i32, i32, vp, i64, ChanAffine, vp, i64, vp, i64, vp, vp]
     lib.ubr_maxpool_bwd.argtypes = [i32, i32, i32, i32, i32, i32, vp, i64, ChanAffine, vp, i64, vp, i64, vp, i64, vp, vp]
     lib.ubr_logsoftmax_bwd.argtypes = [i32, i32, i32, i32, i32, vp, vp, vp, i64, vp]
-    lib.ubr_pixelwise_nll_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i64, vp, vp]
+    lib.ubr_pixelwise_nll_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i64, vp, vp, vp]
     lib.ubr_pixelwise_nll_bwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i64, vp, vp]
     lib.ubr_confusion.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
     lib.ubr_channel_sum.argtypes = [i32, i64, i32, vp, i64, vp, vp]

@@ -38,13 +38,24 @@ class _NetFn(torch.autograd.Function):
         if ctx.sv is None:
             raise RuntimeError("ubresnet_amd: backward called twice on the same forward pass (saved activations were released)")
         hook = getattr(ctx.model, "_grad_ready_hook", None)
+        accumulating = any(p.requires_grad and p.grad is not None for p in ctx.params)
+        if hook is not None and accumulating:
+            # The data-parallel reducer all-reduces ranges of the flat buffer in place WHILE backward is still running;
+            # with an existing .grad the flat buffer would be added into .grad on the compute stream at the same time
+            # and .grad would no longer alias what was reduced (ranks diverge).  Accumulated passes therefore skip the
+            # early exchange: GradAllReducer.finish() reduces the accumulated .grad tensors instead.
+            hook = None
+            pending = getattr(ctx.model, "_grad_accum_pending", None)
+            if pending is not None:
+                pending()
         flat, views = ctx.eng.backward(ctx.sv, g_out, hook)
         ctx.sv = None
-        ctx.model.__dict__["_ubr_flat_grad"] = flat
         # Parameter gradients are installed directly as views of the flat buffer (zero copy, and the
         # data-parallel all-reduce of `flat` IS the all-reduce of every .grad).  Handing them to autograd's
         # AccumulateGrad instead would clone each of the 165 tensors (it only steals unreferenced tensors).
         # Accumulation semantics are kept: an existing .grad is added to, never overwritten.
+        if not accumulating:
+            ctx.model.__dict__["_ubr_flat_grad"] = flat
         for p in ctx.params:
             if not p.requires_grad:
                 continue
@@ -56,12 +67,33 @@ class _NetFn(torch.autograd.Function):
         return (None, None, None, None) + (None,) * len(ctx.params)
 
 
+_DP_MSG = ("ubresnet_amd: %s is not supported -- the network is one fused autograd node that installs parameter gradients as "
+           "views of a flat buffer, so %s would silently receive no gradients.  Data-parallel training runs one process per "
+           "GPU (torch.distributed, backend 'nccl' = RCCL) with ubresnet_amd.dist.GradAllReducer(model): see INTEGRATION.md "
+           "(replaces nn.DataParallel of training/train_ubresnet2018_wlarcv2.py:99,103).")
+
+
+def _check_wrappers(params, x):
+    """errors must raise: the wrappers below would train on no gradients without any message"""
+    for p in params:
+        if p.requires_grad and not p.is_leaf:
+            raise RuntimeError(_DP_MSG % ("nn.DataParallel replication (parameters are non-leaf broadcast copies)",
+                                          "the master parameters"))
+    ddp = getattr(torch.nn.parallel.DistributedDataParallel, "_active_ddp_module", None)
+    if ddp is not None:
+        raise RuntimeError(_DP_MSG % ("a DistributedDataParallel wrapper", "DDP's gradient hooks"))
+    if x.requires_grad:
+        raise RuntimeError("ubresnet_amd: the input requires grad, but the HIP path computes no input gradient (no caller "
+                           "of the reference needs one); detach the input")
+
+
 def run_network(model, kind: str, x: torch.Tensor) -> torch.Tensor:
     eng = _engine(model, kind)
     dt = compute_dtype(model)
     params = tuple(p for _, p in eng.grad_order)
     need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
     if need_grad:
+        _check_wrappers(params, x)
         return _NetFn.apply(x, model, eng, dt, *params)
     out, _ = eng.forward(x, model.training, dt, False)
     return out

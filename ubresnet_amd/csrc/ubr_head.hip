@@ -252,12 +252,14 @@ __global__ __launch_bounds__(256) void logsoftmax_bwd_kernel(long npix_img, int 
 // PixelWiseNLLLoss
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void nll_fwd_kernel(const float* pred, const long long* target, const float* pw, const float* cw,
-                                                      int N, int C, long hw, long long ignore_index, double* acc) {
+                                                      int N, int C, long hw, long long ignore_index, double* acc, unsigned long long* bad) {
   __shared__ double part[4];
   const long total = (long)N * hw;
   double s = 0.0;
+  unsigned nbad = 0u;
   for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < total; p += (long)gridDim.x * 256) {
     const long long t = target[p];
+    if (t != ignore_index && (t < 0 || t >= C)) ++nbad;      // F.nll_loss device-asserts on these (reference behaviour)
     if (t != ignore_index && t >= 0 && t < C) {
       const long n = p / hw, r = p - n * hw;
       const float w = cw ? cw[t] : 1.f;
@@ -269,6 +271,7 @@ __global__ __launch_bounds__(256) void nll_fwd_kernel(const float* pred, const l
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) atomicAdd(acc + (blockIdx.x % UBR_STAT_SLOTS), part[0] + part[1] + part[2] + part[3]);
+  if (bad != nullptr && nbad) atomicAdd(bad, (unsigned long long)nbad);
 }
 
 __global__ __launch_bounds__(256) void nll_bwd_kernel(const float* gloss, const long long* target, const float* pw, const float* cw,
@@ -392,14 +395,14 @@ extern "C" int ubr_logsoftmax_bwd(int dtype, int N, int C, int H, int W, const f
 
 extern "C" int ubr_pixelwise_nll_fwd(const float* predict_nchw, const int64_t* target, const float* pixelweights,
                                      const float* classw, int N, int C, int H, int W, int64_t ignore_index,
-                                     double* acc, void* stream) {
+                                     double* acc, unsigned long long* bad_labels, void* stream) {
   UBR_CHECK(predict_nchw && target && pixelweights && acc, "ubr_pixelwise_nll_fwd: null pointer");
   UBR_CHECK(N > 0 && C > 0 && H > 0 && W > 0, "ubr_pixelwise_nll_fwd: bad extents");
   const long hw = (long)H * W;
   long blocks = ((long)N * hw + 255) / 256;
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(nll_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, predict_nchw, (const long long*)target,
-                     pixelweights, classw, N, C, hw, (long long)ignore_index, acc);
+                     pixelweights, classw, N, C, hw, (long long)ignore_index, acc, bad_labels);
   UBR_LAUNCH_CHECK("ubr_pixelwise_nll_fwd");
   return UBR_OK;
 }

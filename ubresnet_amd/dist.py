@@ -16,7 +16,17 @@ import torch.distributed as dist
 
 
 class GradAllReducer:
-    def __init__(self, model, bucket_bytes: int = 16 << 20, group=None):
+    """Replicas start identical: construction broadcasts rank 0's parameters and buffers (nn.DataParallel re-broadcasts
+    device 0's every forward, training/train_ubresnet2018_wlarcv2.py:99; here once is enough because every rank applies the
+    same averaged gradient).  BatchNorm running statistics are NOT exchanged afterwards: each rank tracks its own shard
+    (DataParallel semantics: only replica 0's persist) and a checkpoint written by rank 0 holds rank 0's, exactly what the
+    reference saves; `average_bn_stats()` makes them rank-independent before a checkpoint when that is wanted.
+
+    Gradient accumulation (several backward passes per optimizer step, or zero_grad(set_to_none=False)): the first pass
+    of a step is exchanged bucket by bucket during backward; a pass that finds existing .grad tensors accumulates locally
+    and `finish()` all-reduces the accumulated .grad tensors (see autograd_fn._NetFn.backward)."""
+
+    def __init__(self, model, bucket_bytes: int = 16 << 20, group=None, broadcast_init: bool = True):
         self.model = model
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -31,7 +41,66 @@ class GradAllReducer:
         self.works = []
         self.wait_events = []
         self.use_avg = dist.is_initialized() and dist.get_backend(group) == "nccl"
+        self._accum = False
         model._grad_ready_hook = self._hook
+        model._grad_accum_pending = self._begin_accumulate
+        if broadcast_init and self.world > 1 and hasattr(model, "parameters"):
+            self.broadcast_state()
+
+    def _tensors(self, what):
+        return [t for t in (self.model.parameters() if what == "params" else self.model.buffers())]
+
+    def broadcast_state(self, src: int = 0):
+        """rank `src`'s parameters and buffers to every rank (one coalesced broadcast per dtype)"""
+        from torch._utils import _flatten_dense_tensors, _unflatten_dense_tensors
+        with torch.no_grad():
+            by_dtype = {}
+            for t in self._tensors("params") + self._tensors("buffers"):
+                by_dtype.setdefault(t.dtype, []).append(t.data)
+            for ts in by_dtype.values():
+                flat = _flatten_dense_tensors(ts)
+                dist.broadcast(flat, src, group=self.group)
+                for t, v in zip(ts, _unflatten_dense_tensors(flat, ts)):
+                    t.copy_(v)
+
+    def average_bn_stats(self):
+        """mean over ranks of every floating-point buffer (BatchNorm running_mean / running_var): optional, for
+        rank-independent checkpoints; integer buffers (num_batches_tracked) are equal on every rank already"""
+        if self.world == 1:
+            return
+        from torch._utils import _flatten_dense_tensors, _unflatten_dense_tensors
+        with torch.no_grad():
+            ts = [b.data for b in self._tensors("buffers") if b.dtype.is_floating_point]
+            if not ts:
+                return
+            flat = _flatten_dense_tensors(ts)
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            flat.div_(self.world)
+            for t, v in zip(ts, _unflatten_dense_tensors(flat, ts)):
+                t.copy_(v)
+
+    def _drain(self):
+        """compute stream waits for every bucket in flight; the flat buffer is then final (averaged)"""
+        if self.flat is None:
+            return
+        if self.pending_hi is not None and self.pending_hi > self.pending_lo:
+            self._launch(self.pending_lo, self.pending_hi)
+            self.pending_lo = self.pending_hi
+        for w in self.works:
+            w.wait()
+        self.works = []
+        if self.flat.is_cuda and self.stream is not None:
+            torch.cuda.current_stream(self.flat.device).wait_stream(self.stream)
+        if not self.use_avg:
+            self.flat.div_(self.world)
+        self.flat = None
+
+    # called by _NetFn.backward before a pass that will ADD into existing .grad tensors
+    def _begin_accumulate(self):
+        if self.world == 1 and not self.force:
+            return
+        self._drain()          # an earlier pass's buckets must land before .grad (their alias) is added to
+        self._accum = True
 
     # called by the executor on the compute stream: flat[lo:hi] is final once the compute stream AND every event in
     # wait_events (work the executor queued on its other streams) have been reached
@@ -71,19 +140,21 @@ class GradAllReducer:
 
     def finish(self):
         """make the compute stream wait for every outstanding bucket (call before optimizer.step)"""
-        if (self.world == 1 and not self.force) or self.flat is None:
+        if self.world == 1 and not self.force:
             return
-        if self.pending_hi is not None and self.pending_hi > self.pending_lo:
-            self._launch(self.pending_lo, self.pending_hi)
-            self.pending_lo = self.pending_hi
-        for w in self.works:
-            w.wait()
-        self.works = []
-        if self.flat.is_cuda and self.stream is not None:
-            torch.cuda.current_stream(self.flat.device).wait_stream(self.stream)
-        if not self.use_avg:
-            self.flat.div_(self.world)
-        self.flat = None
+        self._drain()
+        if self._accum:
+            # accumulated passes were not exchanged during backward: reduce the .grad tensors themselves
+            from torch._utils import _flatten_dense_tensors, _unflatten_dense_tensors
+            self._accum = False
+            gs = [p.grad for p in self._tensors("params") if p.grad is not None]
+            if gs:
+                flat = _flatten_dense_tensors(gs)
+                dist.all_reduce(flat, op=dist.ReduceOp.AVG if self.use_avg else dist.ReduceOp.SUM, group=self.group)
+                if not self.use_avg:
+                    flat.div_(self.world)
+                for g, v in zip(gs, _unflatten_dense_tensors(flat, gs)):
+                    g.copy_(v)
 
 
 def shard_range(global_batch: int, rank: int, world: int):

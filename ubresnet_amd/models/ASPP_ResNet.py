@@ -12,7 +12,7 @@ As in the reference the network is only consistent for inplanes=16 (the ASPP bra
 hard-wired to 16 so `inplanes*12/20/36` at :343-351 only match then); other values raise.
 The reference file also imports `commands`, ROOT, larcv and torchvision (:22,31,32,45-47); none of
 them is used by the model, so they are not imported here.  `ASPP_ResNet1` (the module name the
-reference's train scripts import, Sem_Seg_ASPP_ResNet1.py:43) is provided as an alias file.
+reference's train scripts import, Sem_Seg_ASPP_ResNet1.py:43) is the alias module ASPP_ResNet1.py next to this file.
 """
 import math
 import os

@@ -451,10 +451,10 @@ def logsoftmax_bwd(g_logp, logp, g_logits):
                                        g_logits.data_ptr(), _ps(g_logits), L.stream_ptr()), "logsoftmax_bwd")
 
 
-def pixelwise_nll_fwd(predict, target, pixelweights, classw, ignore_index, acc):
+def pixelwise_nll_fwd(predict, target, pixelweights, classw, ignore_index, acc, bad=None):
     N, Cn, H, W = predict.shape
     L.check(L.lib().ubr_pixelwise_nll_fwd(predict.data_ptr(), target.data_ptr(), pixelweights.data_ptr(), L.ptr(classw),
-                                          N, Cn, H, W, int(ignore_index), acc.data_ptr(), L.stream_ptr()), "pixelwise_nll_fwd")
+                                          N, Cn, H, W, int(ignore_index), acc.data_ptr(), L.ptr(bad), L.stream_ptr()), "pixelwise_nll_fwd")
 
 
 def pixelwise_nll_bwd(g_loss, target, pixelweights, classw, ignore_index, shape, g_predict):

@@ -75,6 +75,12 @@ class _FlatOptimizer(torch.optim.Optimizer):
                     break
         if ok:
             return g
+        have = [p.grad is not None for _, p, _ in self._layout]
+        if not any(have):
+            return None          # torch.optim skips parameters without a gradient: nothing to do
+        if not all(have):
+            raise RuntimeError("ubresnet_amd.optim: some parameters have no gradient (frozen / requires_grad=False); the flat "
+                               "one-launch step updates every parameter -- use torch.optim for partially frozen models")
         if self._scratch is None:
             self._scratch = torch.zeros_like(self.flat)
         else:
@@ -110,6 +116,8 @@ class FlatAdam(_FlatOptimizer):
         loss = closure() if closure is not None else None
         self._check_views()
         g = self._flat_grad()
+        if g is None:
+            return loss
         grp = self.param_groups[0]
         self.steps += 1
         L.check(L.lib().ubr_adam_step(self.flat.data_ptr(), g.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
@@ -153,6 +161,8 @@ class FlatSGD(_FlatOptimizer):
         loss = closure() if closure is not None else None
         self._check_views()
         g = self._flat_grad()
+        if g is None:
+            return loss
         grp = self.param_groups[0]
         first = self.steps == 0
         self.steps += 1

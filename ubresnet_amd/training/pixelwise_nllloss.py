@@ -34,6 +34,47 @@ def _assert_no_grad(variable):
         "mark these variables as not requiring gradients"
 
 
+class _LabelCheck:
+    """F.nll_loss raises (device assert) for a target outside [0,C) other than ignore_index
+    (training/pixelwise_nllloss.py:51); the HIP kernel counts such labels instead.  The count is copied to pinned host
+    memory asynchronously and examined when it has landed -- at the next loss call (no host/device sync is added to
+    the step), or immediately with UBR_CHECK_LABELS=sync; UBR_CHECK_LABELS=0 disables the report."""
+
+    def __init__(self):
+        self.pending = []
+        self.free = []         # recycled (event, pinned int64) pairs: pinning memory is far too slow to do per step
+        self.mode = os.environ.get("UBR_CHECK_LABELS", "async")
+
+    def _raise(self, n, C, ign):
+        raise RuntimeError("PixelWiseNLLLoss: %d target label(s) outside [0, %d) and different from ignore_index=%d "
+                           "(F.nll_loss would assert); check the dataset's class ids" % (n, C, ign))
+
+    def watch(self, bad_dev, C, ign):
+        if self.mode == "0" or torch.cuda.is_current_stream_capturing():
+            return
+        ev, host = self.free.pop() if self.free else (torch.cuda.Event(), torch.empty(1, dtype=torch.int64).pin_memory())
+        host.copy_(bad_dev.view(torch.int64), non_blocking=True)
+        ev.record()
+        self.pending.append((ev, host, int(C), int(ign)))
+        if self.mode == "sync":
+            ev.synchronize()
+            self.poll()
+
+    def poll(self):
+        if self.pending and torch.cuda.is_current_stream_capturing():
+            return
+        while self.pending and self.pending[0][0].query():
+            ev, host, C, ign = self.pending.pop(0)
+            n = int(host.item())
+            self.free.append((ev, host))
+            if n:
+                self.pending.clear()
+                self._raise(n, C, ign)
+
+
+_label_check = _LabelCheck()
+
+
 class _PixelNLLFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, predict, target, pixelweights, classw, ignore_index):
@@ -46,8 +87,11 @@ class _PixelNLLFn(torch.autograd.Function):
             raise RuntimeError("PixelWiseNLLLoss: shape mismatch predict %s target %s pixelweights %s"
                                % (tuple(predict.shape), tuple(target.shape), tuple(pixelweights.shape)))
         predict, target, pixelweights = predict.contiguous(), target.contiguous(), pixelweights.contiguous()
-        acc = ops.stat_buffer(1, predict.device)
-        ops.pixelwise_nll_fwd(predict, target, pixelweights, classw, ignore_index, acc)
+        _label_check.poll()
+        acc = torch.empty(L.STAT_SLOTS + 1, dtype=torch.float64, device=predict.device)   # [slots of the sum | bad-label count (u64)]
+        ops.zero_(acc)
+        ops.pixelwise_nll_fwd(predict, target, pixelweights, classw, ignore_index, acc, bad=acc[L.STAT_SLOTS:])
+        _label_check.watch(acc[L.STAT_SLOTS:], predict.shape[1], ignore_index)
         loss = torch.empty((), dtype=torch.float32, device=predict.device)
         ops.cast_f64_to_f32(acc, loss, 1, 1.0 / float(target.numel()), stride=1)
         ctx.save_for_backward(target, pixelweights)
