@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--optimizer", choices=["flat", "torch"], default="flat", help="flat: ubresnet_amd.optim.FlatAdam (one launch); torch: torch.optim.Adam(fused=True)")
     ap.add_argument("--no-breakdown", action="store_true")
+    ap.add_argument("--no-infer", action="store_true", help="skip the whole-view inference leg (BASELINE configs[4])")
     ap.add_argument("--breakdown-file", default="")
     return ap.parse_args()
 
@@ -62,7 +63,7 @@ def host_cores():
             n = max(1, min(n, int(float(q) / float(per))))
     except Exception:
         pass
-    return max(1, min(n, int(os.environ.get("UBR_CPU_THREADS", "16"))))
+    return max(1, min(n, int(os.environ.get("UBR_CPU_THREADS", str(n)))))
 
 
 def cpu_baseline(size, inplanes, seconds_budget=20.0):
@@ -128,6 +129,39 @@ def cpu_baseline(size, inplanes, seconds_budget=20.0):
     return {"value": B * n / el, "unit": "images/sec", "cores": cores, "kind": "port",
             "sample": "%d timed train steps (1 warm-up) of the CPU oracle, UResNet ip%d fp32, batch %d, %dx%d, Adam" % (n, inplanes, B, size, size),
             "ms_per_step": 1e3 * el / n, "iou_vs_reference": iou}
+
+
+def infer_leg(events=6, warmup=2):
+    """BASELINE.json configs[4] on the same GPU, outside the train timed region: whole-view inference, 3 x 1008 x 3456 event
+    = 30 tiles of 512x832, UResNet(ip16, 4 classes; deploy/ubresnet_funcs.py:43), fp16 storage / fp32 accumulate, BatchNorm
+    folded, three hipGraph replays of 10 tiles per event (deploy/run_ubresnet_wholeview.py:191-277 shape)."""
+    import numpy as np
+    from ubresnet_amd import deploy, synthetic
+    torch.manual_seed(7)
+    m = deploy.load_model(None, "cuda:%d" % torch.cuda.current_device(), num_classes=4)
+    rows, cols = 1008, 3456
+    adc = np.zeros((3, 1, rows, cols), np.float32)
+    for p in range(3):
+        adc[p, 0] = synthetic.make_crop(rows, cols, 5000 + p)[0]
+    view = torch.from_numpy(adc).cuda()
+    seg = deploy.WholeViewSegmenter(m, rows, cols, planes=3, tile=(512, 832), batch=10, dtype=torch.float16, use_graph=True)
+    for _ in range(warmup):
+        seg(view)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(events):
+        seg(view)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    nt = seg.tiles_per_event
+    gb_tile = 0.654e9        # SURVEY.md section 8d: 201.2 M elements per 512^2 image x (512*832 / 512^2) x 2 B
+    ach = gb_tile * nt * events / el / 1e9
+    return {"metric": "tiles/sec, whole-view 3456x1008 tiled inference (512x832 tiles, forward only, fp16, hipGraph)",
+            "value": nt * events / el, "unit": "tiles/sec", "events_per_sec": events / el, "ms_per_event": 1e3 * el / events,
+            "tiles_per_event": nt, "events_timed": events, "dtype": "f16", "hipgraph": True, "n_gpus": 1, "data": "synthetic",
+            "config": {"workload": "UResNet ip16 4-class eval, 3x1008x3456 views -> 30 tiles of 512x832, 3 graph replays of 10 tiles"},
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_tile": gb_tile, "scope": "whole event (crop + 3 replays + stitch)"}}
 
 
 def main():
@@ -269,6 +303,12 @@ def main():
                 f.write("\n== by (op, shape) ==\n%-14s %-62s %5s %10s %9s %9s %7s\n" % ("op", "shape", "n", "total_ms", "GB/s", "TFLOP/s", "share"))
                 for (nm, sg), (c_, t_, b_, fl_) in sorted(prof.summary(by="shape").items(), key=lambda kv: -kv[1][1]):
                     f.write("%-14s %-62s %5d %10.3f %9.1f %9.1f %6.1f%%\n" % (nm, sg, c_, 1e3 * t_, b_ / max(t_, 1e-12) / 1e9, fl_ / max(t_, 1e-12) / 1e12, 100 * t_ / tot))
+    if rank == 0 and world == 1 and not a.no_infer:
+        del model, opt
+        try:
+            res["infer"] = infer_leg()
+        except Exception as e:          # the secondary leg must never take the headline line down
+            res["infer"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(a.size, a.inplanes)
     if rank == 0:

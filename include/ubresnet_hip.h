@@ -67,6 +67,7 @@ typedef struct {
  *   and the data gradients of both (what autograd's ConvolutionBackward computes).
  * out(oy,ox,co) = bias[co] + addend(oy,ox,co)
  *               + sum_t sum_ci  xform(x)(oy*S + iy0 + dy[t], ox*S + ix0 + dx[t], ci) * w[wt[t]][ci][co]
+ * (optionally with ReLUs around the addend, see `act`)
  * `w` is the packed image written by ubr_pack_weights.  `y` is a view of the output grid
  * (OH x OW); phase decompositions pass a view with doubled strides.
  * stats (optional): stats[co] += sum over the grid of out, stats[Cout+co] += sum of out^2
@@ -92,6 +93,10 @@ typedef struct {
   double* stats;             /* NULL: none */
   int32_t epilogue;          /* 0 store T NHWC, 1 log-softmax to fp32 NCHW */
   int32_t tile_hint;         /* 0 auto */
+  int32_t act;               /* inference epilogue (BatchNorm folded into w/bias): bit 0 = ReLU before the addend,
+                              * bit 1 = ReLU after it:  out = relu?( relu?(conv + bias) + addend )  -- with both bits
+                              * this is the whole BasicBlock tail (models/common_layers.py:47-56) */
+  int32_t pad_;
 } ubr_conv_desc;
 
 int ubr_conv(const ubr_conv_desc* d, void* stream);
@@ -114,9 +119,23 @@ typedef struct {
   const float* src;
   void* dst;
   int64_t sm, sk, tap_stride;
+  const float* oscale;       /* optional per-row (m) multiplier: BatchNorm folded into the weights for inference; NULL = 1 */
   int32_t M, Mpad, Kvalid, KU, ntaps, pad_;
 } ubr_pack_item;
 int ubr_pack_weights_batched(int dtype, const ubr_pack_item* items_dev, int nitems, void* stream);
+
+/* Inference: eval-mode BatchNorm2d folded into the convolution in front of it (deploy/run_ubresnet_precropped.py:88-89
+ * runs model.eval()).  For every site:  scale = gamma/sqrt(running_var+eps)  (goes into ubr_pack_item.oscale) and
+ * bias = (conv_bias - running_mean)*scale + beta  (goes into ubr_conv_desc.bias), computed in fp64.  items_dev is a
+ * DEVICE array; one launch for all sites of a network. */
+typedef struct {
+  const float *gamma, *beta, *running_mean, *running_var;
+  const float* conv_bias;    /* NULL: the convolution has no bias */
+  float *scale, *bias;       /* outputs, C floats each */
+  int32_t C;
+  float eps;
+} ubr_bn_fold_item;
+int ubr_bn_fold_batched(const ubr_bn_fold_item* items_dev, int nitems, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Weight gradient (autograd ConvolutionBackward, weight part) on MFMA with pixels as K.

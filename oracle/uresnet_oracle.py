@@ -366,3 +366,19 @@ def train_step_grads(forward_fn, sd: Mapping[str, Tensor], x: Tensor, target: Te
     names = [k for k in p if is_param_key(k)]
     gs = torch.autograd.grad(loss, [p[k] for k in names])
     return loss.detach(), OrderedDict(zip(names, gs)), logp.detach(), ns
+
+
+def state_dict_with_bn_stats(sd: Mapping[str, Tensor], keys, flat) -> "OrderedDict[str, Tensor]":
+    """copy of `sd` whose BatchNorm running statistics are replaced by the fixture's (tests/golden/*norm*.npz store
+    them as one flat float32 vector `bn_stats` in the order of `bn_keys`: they are part of the fixture's INPUT, produced
+    by the reference model's own train-mode calibration passes, tests/golden/make_golden.py::calibrate_running_stats)"""
+    import numpy as np
+    out = OrderedDict((k, v.clone()) for k, v in sd.items())
+    off = 0
+    flat = np.asarray(flat, dtype=np.float32)
+    for k in [str(k) for k in keys]:
+        n = out[k].numel()
+        out[k] = torch.from_numpy(flat[off:off + n].copy()).reshape(out[k].shape)
+        off += n
+    assert off == flat.shape[0]
+    return out

@@ -10,7 +10,8 @@ this script.  Version shims (torch 0.4 -> 2.x): ``crit.size_a
 for the backward fixtures each BasicBlock.relu2 is replaced by nn.Threshold(0,0) so the
 reference's in-place residual add (models/common_layers.py:52,54) is differentiable.
 
-Usage:  python tests/golden/make_golden.py
+Usage:  python tests/golden/make_golden.py            # every fixture
+        python tests/golden/make_golden.py --only norm   # only the normalised-eval (deployment) fixtures
 """
 import hashlib
 import os
@@ -90,10 +91,64 @@ def run_train_step(model, crit, x, lab, wgt):
     return out.detach().numpy(), float(loss.item())
 
 
+def calibrate_running_stats(model, batches):
+    """Deployment-like BatchNorm statistics for seeded (untrained) weights: the REFERENCE model itself is run in train
+    mode over calibration batches with cumulative averaging (momentum=None, statistics reset first), so its running
+    statistics become the mean of the batch statistics it saw and eval-mode activations are O(1) -- what a trained
+    checkpoint looks like to the inference path (and what keeps fp16 inside its range)."""
+    for m in model.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.reset_running_stats()
+            m.momentum = None
+    model.train()
+    with torch.no_grad():
+        for xb in batches:
+            model.forward(torch.from_numpy(xb))
+    model.eval()
+    return model
+
+
+def norm_fixtures(ub):
+    """eval-mode fixtures with normalising running statistics (BASELINE configs[4] parity: fp32 and fp16 forward of
+    deploy/run_ubresnet_wholeview.py-shaped tiles, UResNet(ip16, 1 plane, 4 classes) of deploy/ubresnet_funcs.py:43)"""
+    sd4 = O.seeded_state_dict(O.uresnet_schema(4, 1, 16, 16), 43)
+    bn_keys = [k for k in sd4 if k.endswith("running_mean") or k.endswith("running_var")]
+    for tag, (H, W, seed_x, seed_cal) in {"1x1x64x96": (64, 96, 1200, 1400), "1x1x512x832": (512, 832, 1500, 1600)}.items():
+        m = ub.UResNet(num_classes=4, input_channels=1, inplanes=16)
+        m.load_state_dict(sd4)
+        cal = [synthetic.make_batch(2, H, W, seed_cal + 10 * i)[0] for i in range(2)]
+        calibrate_running_stats(m, cal)
+        after = m.state_dict()
+        x = synthetic.make_batch(1, H, W, seed_x)[0]
+        with torch.no_grad():
+            out = m.forward(torch.from_numpy(x))
+        stats = np.concatenate([after[k].numpy().reshape(-1) for k in bn_keys]).astype(np.float32)
+        am = out.max(1)[1].numpy().astype(np.uint8)
+        top2 = torch.topk(out, 2, dim=1)[0]
+        margin = (top2[:, 0] - top2[:, 1]).numpy().reshape(-1)
+        common = dict(bn_keys=np.array(bn_keys), bn_stats=stats, meta=np.array([1, 1, H, W, seed_x, 43]),
+                      absmax=np.float32(out.abs().max().item()))
+        if H * W <= 64 * 96:
+            np.savez_compressed(os.path.join(HERE, "uresnet_ip16_nc4_norm_%s.npz" % tag), logp_eval=out.numpy().astype(np.float32), **common)
+        else:
+            idx = sample_indices(out.numel(), 4096, 13)
+            np.savez_compressed(
+                os.path.join(HERE, "uresnet_ip16_nc4_norm_%s_summary.npz" % tag),
+                sample_idx=idx, sample_logp_eval=out.numpy().reshape(-1)[idx],
+                argmax=am, argmax_sha256=np.array(hashlib.sha256(am.tobytes()).hexdigest()),
+                class_counts=np.bincount(am.reshape(-1), minlength=4),
+                safe_0p02=np.packbits(margin > 0.02), safe_0p2=np.packbits(margin > 0.2),
+                margin_hist=np.histogram(margin, bins=[0, 1e-4, 1e-3, 1e-2, 1e-1, 1, 10, 1e9])[0], **common)
+        print("norm fixture", tag, "absmax logp %.3f" % out.abs().max().item(), "class counts", np.bincount(am.reshape(-1), minlength=4))
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     ub, aspp, pl, cl = import_reference()
+    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "norm":
+        norm_fixtures(ub)
+        return
 
     # ---------------- schema check: our key order/shape == reference state_dict -------------
     for ctor, schema in (
@@ -235,6 +290,7 @@ def main():
         **{"gs__" + k: v for k, v in samples.items()},
         meta=np.array([2, 1, 512, 512, 1000, 42]))
     print("512 summary loss", loss, "counts", np.bincount(am.reshape(-1), minlength=3))
+    norm_fixtures(ub)
 
 
 if __name__ == "__main__":

@@ -508,3 +508,81 @@ def test_out_of_range_labels_raise():
         PL._label_check.mode = old
         PL._label_check.pending.clear()
     assert abs(float(crit(lp, tg, pw)) - float(good)) < 1e-7
+
+
+@pytest.mark.parametrize("dt", DTS + [torch.float16])
+@pytest.mark.parametrize("act", [1, 2, 3])
+def test_conv_inference_epilogue(dt, act):
+    """ubr_conv_desc.act: out = relu?( relu?(conv + bias) + addend ) -- the BasicBlock tail of the inference schedule
+    (models/common_layers.py:47-56 with eval-mode BatchNorm folded into weights and bias)"""
+    N, H, W, Cin, Cout = 2, 16, 32, 32, 32
+    x = rnd(dt, gen(N, Cin, H, W, seed=1))
+    w = gen(Cout, Cin, 3, 3, seed=2, scale=(2.0 / (9 * Cin)) ** 0.5)
+    b = gen(Cout, seed=3) * 0.5
+    ad = rnd(dt, gen(N, Cout, H, W, seed=6))
+    ref = F.conv2d(x, rnd(dt, w), b, 1, 1)
+    if act & 1:
+        ref = F.relu(ref)
+    ref = ref + ad
+    if act & 2:
+        ref = F.relu(ref)
+    y = torch.empty((N, H, W, Cout), dtype=dt, device=DEV)
+    wp = ops.pack_weights(w.to(DEV), dt, Cout, Cin, Cin * 9, 9, 9)
+    ops.conv(nhwc(x, dt), wp, y, ops.conv_taps(3, 1, 1), Cout, bias=b.to(DEV), addend=nhwc(ad, dt), act=act)
+    torch.cuda.synchronize()
+    close(nchw(y), ref, tol(dt), "conv act=%d" % act)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_batched_pack_and_bn_fold(dt):
+    """ubr_pack_weights_batched (coalesced LDS transpose; both dense orientations, the gather path, an output-row
+    scale) against ubr_pack_weights item by item, and ubr_bn_fold_batched against its fp64 formula"""
+    import struct
+    from ubresnet_amd import _lib as L
+    cpu = L.chans_per_unit(dt)
+    cases = []      # (weight, M, Kvalid, Kpad, sm, sk, ntaps, tap_stride, src_offset, scaled)
+    for (d0, d1, k, seed) in ((48, 24, 3, 1), (16, 40, 7, 2), (3, 16, 7, 3), (64, 64, 1, 4), (32, 16, 4, 5)):
+        w = gen(d0, d1, k, k, seed=seed).to(DEV)
+        kk = k * k
+        cases.append((w, d0, d1, None, d1 * kk, kk, kk, 1, 0, True))         # Conv2d forward orientation (mode A), scaled rows
+        cases.append((w, d1, d0, None, kk, d1 * kk, kk, 1, 0, False))        # data-gradient orientation (mode B)
+    w7 = gen(16, 2, 7, 7, seed=9).to(DEV)
+    cases.append((w7, 16, 7, 16, 2 * 49, 1, 7, 7, 49, True))                 # column-expanded stem, plane 1 (gather path)
+    items, dsts, refs, keep = b"", [], [], []
+    for (w, M, Kv, Kpad, sm, sk, ntaps, tstride, soff, scaled) in cases:
+        Mpad = (M + 15) // 16 * 16
+        Kp = Kpad if Kpad is not None else (Kv + cpu - 1) // cpu * cpu
+        dst = torch.full((ntaps, Kp // cpu, Mpad, cpu), 5.0, dtype=dt, device=DEV)
+        sc = (gen(M, seed=11).abs() + 0.5).to(DEV) if scaled else None
+        keep.append(sc)            # the table holds raw device addresses: the scale vectors must outlive the launch
+        items += struct.pack("<QQqqqQiiiiii", w.data_ptr() + 4 * soff, dst.data_ptr(), sm, sk, tstride, sc.data_ptr() if scaled else 0,
+                             M, Mpad, Kv, Kp // cpu, ntaps, 0)
+        dsts.append(dst)
+        wsrc = w
+        if scaled:     # scaling rows of the source == scaling output rows (M indexes dim 0 in the scaled cases)
+            wsrc = (w * sc.view(-1, 1, 1, 1)).contiguous()
+        refs.append(ops.pack_weights(wsrc, dt, M, Kv, sm, sk, ntaps, tapidx=[t * tstride for t in range(ntaps)], Kpad=Kp, src_offset=soff))
+    tbl = torch.frombuffer(bytearray(items), dtype=torch.uint8).to(DEV)
+    L.check(L.lib().ubr_pack_weights_batched(L.dtype_id(dt), tbl.data_ptr(), len(cases), L.stream_ptr()), "pack")
+    torch.cuda.synchronize()
+    for i, (got, ref) in enumerate(zip(dsts, refs)):
+        if dt == torch.float32 and cases[i][-1]:
+            assert torch.allclose(got, ref, rtol=2e-7, atol=0), "item %d" % i      # w*s rounded once on either side
+        elif cases[i][-1]:
+            assert (got.float() - ref.float()).abs().max() <= 2 ** -7 * ref.float().abs().max(), "item %d" % i   # 1 bf16 ulp
+        else:
+            assert torch.equal(got, ref), "item %d" % i
+    # BatchNorm fold
+    Cn = 40
+    gam, bet, rm = gen(Cn, seed=1).to(DEV), gen(Cn, seed=2).to(DEV), gen(Cn, seed=3).to(DEV)
+    rv, cb = (gen(Cn, seed=4).abs() + 0.1).to(DEV), gen(Cn, seed=5).to(DEV)
+    out = torch.zeros(4 * Cn, device=DEV)
+    it = struct.pack("<QQQQQQQif", gam.data_ptr(), bet.data_ptr(), rm.data_ptr(), rv.data_ptr(), cb.data_ptr(), out.data_ptr(), out[Cn:].data_ptr(), Cn, 1e-5)
+    it += struct.pack("<QQQQQQQif", gam.data_ptr(), bet.data_ptr(), rm.data_ptr(), rv.data_ptr(), 0, out[2 * Cn:].data_ptr(), out[3 * Cn:].data_ptr(), Cn, 1e-5)
+    t2 = torch.frombuffer(bytearray(it), dtype=torch.uint8).to(DEV)
+    L.check(L.lib().ubr_bn_fold_batched(t2.data_ptr(), 2, L.stream_ptr()), "fold")
+    torch.cuda.synchronize()
+    s = gam.double() / torch.sqrt(rv.double() + 1e-5)
+    assert torch.allclose(out[:Cn].double(), s, rtol=1e-6) and torch.allclose(out[2 * Cn:3 * Cn].double(), s, rtol=1e-6)
+    assert torch.allclose(out[Cn:2 * Cn].double(), (cb.double() - rm.double()) * s + bet.double(), rtol=1e-6, atol=1e-6)
+    assert torch.allclose(out[3 * Cn:].double(), (0 - rm.double()) * s + bet.double(), rtol=1e-6, atol=1e-6)

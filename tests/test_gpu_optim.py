@@ -117,8 +117,14 @@ def test_flat_adam_gathers_when_grads_are_not_the_flat_views():
     ob = torch.optim.Adam(mb.parameters(), lr=1e-3)
     x, lab, wgt = _batch(0)
     crit(ma(x), lab, wgt).backward()
+    first = ma.__dict__["_ubr_flat_grad"]
+    g1 = first.clone()
     crit(ma(x), lab, wgt).backward()              # second backward ACCUMULATES into the first pass's buffers
-    assert oa._flat_grad() is not ma.__dict__["_ubr_flat_grad"]
+    # the .grad tensors still alias the first pass's flat buffer, which now holds the accumulated sum: used as is
+    assert oa._flat_grad() is first and torch.allclose(first, 2 * g1, rtol=1e-5, atol=1e-9)
+    # gradients replaced by foreign tensors (e.g. clipped copies) are gathered into a scratch buffer instead
+    ma.conv11.weight.grad = ma.conv11.weight.grad.clone()
+    assert oa._flat_grad() is not first
     for p, q in zip(ma.parameters(), mb.parameters()):
         q.grad = p.grad.detach().clone()
     oa.step()

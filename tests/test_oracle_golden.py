@@ -147,3 +147,25 @@ def test_accuracy_and_confusion():
         n = cm[c].sum().item()
         assert abs(acc[c] - (100.0 * cm[c, c].item() / n if n else 0.0)) < 1e-9
     assert abs(acc[3] - 100.0 * cm.diag().sum().item() / cm.sum().item()) < 1e-9
+
+
+@pytest.mark.parametrize("tag", ["1x1x64x96", "1x1x512x832_summary"])
+def test_uresnet_nc4_normalised_eval(golden_dir, tag):
+    """deployment-shaped fixtures: 4 classes (deploy/ubresnet_funcs.py:43), running statistics calibrated by the
+    reference itself so that eval activations are O(1) (the fp16 inference parity tests build on these)"""
+    g = _load(golden_dir, "uresnet_ip16_nc4_norm_%s.npz" % tag)
+    B, C, H, W, seed0, wseed = [int(v) for v in g["meta"]]
+    sd = O.state_dict_with_bn_stats(O.seeded_state_dict(O.uresnet_schema(4, C, 16, 16), wseed), g["bn_keys"], g["bn_stats"])
+    x, _, _ = synthetic.make_batch(B, H, W, seed0)
+    with torch.no_grad():
+        out = O.uresnet_forward(sd, torch.from_numpy(x), train=False).numpy()
+    assert float(np.abs(out).max()) < 100.0            # normalised: nowhere near the 1e5 of uncalibrated seeded statistics
+    if "logp_eval" in g.files:
+        assert np.abs(out - g["logp_eval"]).max() <= 2e-5
+    else:
+        assert np.abs(out.reshape(-1)[g["sample_idx"]] - g["sample_logp_eval"]).max() <= 1e-4
+        am = out.argmax(1).astype(np.uint8)
+        safe = np.unpackbits(g["safe_0p02"])[:am.size].astype(bool)
+        assert np.array_equal(am.reshape(-1)[safe], g["argmax"].reshape(-1)[safe])
+        if int(g["margin_hist"][:2].sum()) == 0:       # no pixel with a top-2 margin below 1e-3: the class map is pinned bit for bit
+            assert hashlib.sha256(am.tobytes()).hexdigest() == str(g["argmax_sha256"])

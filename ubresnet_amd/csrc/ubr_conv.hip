@@ -39,7 +39,7 @@ struct ConvK {
   int x_sy32, x_sx32;                            // input row / pixel strides in bytes (per-image offsets fit 31 bits)
   int step_j, step_hy, step_goff, wrap_goff;     // halo walk: advance of (column item, row, byte offset) per 256 items
   int wl_off, halo_off, red_off;                 // LDS carve offsets
-  int epilogue;
+  int epilogue, act;
   int8_t dy[UBR_MAX_TAPS], dx[UBR_MAX_TAPS];
   uint8_t wt[UBR_MAX_TAPS];
 };
@@ -334,11 +334,19 @@ __global__ __launch_bounds__(256, ((NT == 4 && FW <= 2 && !PIPE) ? 4 : 2)) void 
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bs[j][r];
+      if (k.act & 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      }
       if (k.ad != nullptr && valid && ch < k.Cout) {
         float a4[4];
         load4<T>(k.ad + (long)n * k.a_sn + (long)oy * k.a_sy + (long)ox * k.a_sx + (long)ch * ESZ, a4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += a4[r];
+      }
+      if (k.act & 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
       }
       if (k.stats != nullptr && valid) {
 #pragma unroll
@@ -527,8 +535,9 @@ extern "C" int ubr_conv(const ubr_conv_desc* d, void* stream) {
                 "ubr_conv: addend view must be aligned to 4 elements");
   } else {
     UBR_CHECK(d->epilogue == 1 && d->Cout <= 16 && d->Cout_pad == 16, "ubr_conv: log-softmax epilogue needs Cout<=16");
-    UBR_CHECK(d->addend.p == nullptr && d->stats == nullptr, "ubr_conv: log-softmax epilogue takes no addend/stats");
+    UBR_CHECK(d->addend.p == nullptr && d->stats == nullptr && d->act == 0, "ubr_conv: log-softmax epilogue takes no addend/stats/act");
   }
+  UBR_CHECK((d->act & ~3) == 0, "ubr_conv: bad act flags %d", d->act);
   int dymin = 127, dymax = -128, dxmin = 127, dxmax = -128;
   for (int t = 0; t < d->ntaps; ++t) {
     dymin = d->dy[t] < dymin ? d->dy[t] : dymin; dymax = d->dy[t] > dymax ? d->dy[t] : dymax;
@@ -587,7 +596,7 @@ extern "C" int ubr_conv(const ubr_conv_desc* d, void* stream) {
   k.step_goff = k.step_hy * k.x_sy32 + (k.step_j >> k.lgUPB) * k.x_sx32;
   k.wrap_goff = k.x_sy32 - best.HW * k.x_sx32;
   k.wl_off = best.wl_off; k.halo_off = best.halo_off; k.red_off = best.red_off;
-  k.epilogue = d->epilogue;
+  k.epilogue = d->epilogue; k.act = d->act;
   for (int t = 0; t < d->ntaps; ++t) { k.dy[t] = d->dy[t]; k.dx[t] = d->dx[t]; k.wt[t] = d->wt[t]; }
 
   const TileCfg& c = kCfgs[best.cfg];
@@ -638,26 +647,107 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackK k) {
 }  // namespace
 
 namespace {
+// All weight images of a network in one launch.  blockIdx.y = item; the workgroups of an item walk its tiles of
+// 16 output rows (m) x KB 16-byte units (k) x all taps.  For the two dense layouts (every Conv2d / ConvTranspose2d
+// weight in either orientation) a tile's source is a handful of CONTIGUOUS runs: they are read coalesced into LDS and
+// transposed from there, and the packed items of a (tap, unit) pair are written as one contiguous 256-byte row.
+// (The first version gathered 4-byte words at a stride of Cin*kh*kw floats: 6.7x over-fetch, 142 us per launch.)
+//   mode A (sk == ntaps): src[m*sm + k*ntaps + t]  -> per m one run over (k, t)      (Conv2d forward, deconv dgrad)
+//   mode B (sm == ntaps): src[k*sk + m*ntaps + t]  -> per k one run over (m, t)      (Conv2d dgrad, deconv forward)
+//   otherwise: per-element gather (column-expanded stem, zero-padded head dgrad: tiny)
+constexpr int kPackLdsFloats = 8192;
 template <typename T>
 __global__ __launch_bounds__(256) void pack_batched_kernel(const ubr_pack_item* items) {
   constexpr int CPU = ET<T>::CPU;
+  __shared__ float lds[kPackLdsFloats + 256];
   const ubr_pack_item it = items[blockIdx.y];
-  const long total = (long)it.ntaps * it.KU * it.Mpad;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int m = (int)(i % it.Mpad);
-    long r = i / it.Mpad;
-    const int ku = (int)(r % it.KU);
-    const int t = (int)(r / it.KU);
-    float f[CPU];
+  const int nt = it.ntaps;
+  const bool modeA = it.tap_stride == 1 && it.sk == nt;
+  const bool modeB = it.tap_stride == 1 && it.sm == nt && !modeA;
+  if (!modeA && !modeB) {
+    const long total = (long)nt * it.KU * it.Mpad;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+      const int m = (int)(i % it.Mpad);
+      long r = i / it.Mpad;
+      const int ku = (int)(r % it.KU);
+      const int t = (int)(r / it.KU);
+      const float sc = (it.oscale != nullptr && m < it.M) ? it.oscale[m] : 1.f;
+      float f[CPU];
 #pragma unroll
-    for (int e = 0; e < CPU; ++e) {
-      const int kc = ku * CPU + e;
-      f[e] = (m < it.M && kc < it.Kvalid) ? it.src[(long)m * it.sm + (long)kc * it.sk + (long)t * it.tap_stride] : 0.f;
+      for (int e = 0; e < CPU; ++e) {
+        const int kc = ku * CPU + e;
+        f[e] = (m < it.M && kc < it.Kvalid) ? it.src[(long)m * it.sm + (long)kc * it.sk + (long)t * it.tap_stride] * sc : 0.f;
+      }
+      *reinterpret_cast<uint4*>((char*)it.dst + i * 16) = ET<T>::pack(f);
     }
-    *reinterpret_cast<uint4*>((char*)it.dst + i * 16) = ET<T>::pack(f);
+    return;
+  }
+  int KB = kPackLdsFloats / (16 * CPU * nt);
+  if (KB > it.KU) KB = it.KU;
+  if (KB > 16) KB = 16;
+  if (KB < 1) KB = 1;
+  const int mtiles = it.Mpad / 16, ktiles = (it.KU + KB - 1) / KB;
+  for (int tile = blockIdx.x; tile < mtiles * ktiles; tile += gridDim.x) {
+    const int m0 = (tile % mtiles) * 16, ku0 = (tile / mtiles) * KB;
+    const int kb = min(KB, it.KU - ku0);                 // units in this tile
+    const int k0 = ku0 * CPU;
+    const int kn = max(0, min(kb * CPU, it.Kvalid - k0));   // valid k values
+    const int mn = max(0, min(16, it.M - m0));            // valid rows
+    __syncthreads();                                      // previous tile fully consumed
+    int rowlen;
+    if (modeA) {        // lds[m][k*nt + t]
+      rowlen = (kb * CPU * nt) | 1;
+      const int run = kn * nt;
+      for (int i = threadIdx.x; i < mn * run; i += 256) {
+        const int m = i / run, c = i - m * run;
+        lds[m * rowlen + c] = it.src[(long)(m0 + m) * it.sm + (long)k0 * nt + c];
+      }
+    } else {            // lds[k][m*nt + t]
+      rowlen = (16 * nt) | 1;
+      const int run = mn * nt;
+      for (int i = threadIdx.x; i < kn * run; i += 256) {
+        const int kk = i / run, c = i - kk * run;
+        lds[kk * rowlen + c] = it.src[(long)(k0 + kk) * it.sk + (long)m0 * nt + c];
+      }
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < nt * kb * 16; o += 256) {
+      const int m = o & 15;
+      const int kul = (o >> 4) % kb, t = (o >> 4) / kb;
+      const float sc = (it.oscale != nullptr && m < mn) ? it.oscale[m0 + m] : 1.f;
+      float f[CPU];
+#pragma unroll
+      for (int e = 0; e < CPU; ++e) {
+        const int kl = kul * CPU + e;
+        float v = 0.f;
+        if (m < mn && kl < kn) v = modeA ? lds[m * rowlen + kl * nt + t] : lds[kl * rowlen + m * nt + t];
+        f[e] = v * sc;
+      }
+      *reinterpret_cast<uint4*>((char*)it.dst + (((long)t * it.KU + ku0 + kul) * it.Mpad + m0 + m) * 16) = ET<T>::pack(f);
+    }
+  }
+}
+
+// BatchNorm (eval) folded into the preceding convolution, all sites of a network in one launch:
+//   scale[c] = gamma/sqrt(running_var+eps)   (multiplies the packed weights, ubr_pack_item.oscale)
+//   bias[c]  = (conv_bias[c] - running_mean[c]) * scale[c] + beta[c]
+__global__ void bn_fold_batched_kernel(const ubr_bn_fold_item* items) {
+  const ubr_bn_fold_item it = items[blockIdx.y];
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < it.C; c += gridDim.x * blockDim.x) {
+    const double s = (double)it.gamma[c] / sqrt((double)it.running_var[c] + (double)it.eps);
+    const double b = it.conv_bias != nullptr ? (double)it.conv_bias[c] : 0.0;
+    it.scale[c] = (float)s;
+    it.bias[c] = (float)((b - (double)it.running_mean[c]) * s + (double)it.beta[c]);
   }
 }
 }  // namespace
+
+extern "C" int ubr_bn_fold_batched(const ubr_bn_fold_item* items_dev, int nitems, void* stream) {
+  UBR_CHECK(items_dev != nullptr && nitems >= 1 && nitems <= 65535, "ubr_bn_fold_batched: bad arguments");
+  hipLaunchKernelGGL(bn_fold_batched_kernel, dim3(4, (unsigned)nitems), dim3(256), 0, (hipStream_t)stream, items_dev);
+  UBR_LAUNCH_CHECK("ubr_bn_fold_batched");
+  return UBR_OK;
+}
 
 extern "C" int ubr_pack_weights_batched(int dtype, const ubr_pack_item* items_dev, int nitems, void* stream) {
   UBR_CHECK(ubr_dtype_ok(dtype), "ubr_pack_weights_batched: bad dtype");

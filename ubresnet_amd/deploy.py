@@ -113,6 +113,7 @@ class WholeViewSegmenter:
         self._graph = None
         self._static_in = None
         self._static_out = None
+        self._captured_sig = None
 
     @property
     def tiles_per_event(self):
@@ -130,9 +131,19 @@ class WholeViewSegmenter:
         finally:
             self.model.compute_dtype = old
 
+    def _signature(self):
+        return tuple(t.data_ptr() for t in self.model.parameters()) + tuple(t.data_ptr() for t in self.model.buffers())
+
     def _ensure_graph(self, device):
+        # the captured graph bakes in the device addresses of parameters, buffers and packed weight images: when the model's
+        # storage was replaced since the capture (model.to(), a flat optimizer adopting the parameters,
+        # load_state_dict(assign=True)) the replay would read freed memory -- capture again
+        sig = self._signature()
+        if self._static_in is not None and sig != self._captured_sig:
+            self._graph = self._static_in = self._static_out = None
         if self._static_in is not None:
             return
+        self._captured_sig = sig
         self._static_in = torch.zeros((self.batch, 1, self.th, self.tw), dtype=torch.float32, device=device)
         self.model.eval()
         with torch.no_grad():

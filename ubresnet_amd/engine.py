@@ -30,6 +30,11 @@ DG1 = ops.conv_dgrad_taps_s1(1, 1, 0)
 DG7 = ops.conv_dgrad_taps_s1(7, 1, 3)
 
 
+import os as _os
+# UBR_INFER_FOLD=0: eval forward on the training schedule (BatchNorm applied on load, separate block tails) -- for A/B tests
+_INFER_FOLD = _os.environ.get("UBR_INFER_FOLD", "1") != "0"
+
+
 def _phase(t, ry, rx):
     """stride-2 phase view of an NHWC tensor"""
     return t[:, ry::2, rx::2, :]
@@ -149,7 +154,7 @@ class Engine:
             Kp = Kpad if Kpad is not None else (Kv + cpu - 1) // cpu * cpu
             dst = torch.empty((ntaps, Kp // cpu, Mpad, cpu), dtype=dt, device=device)
             images[k] = dst
-            tables[group] += struct.pack("<QQqqqiiiiii", w.data_ptr() + 4 * soff, dst.data_ptr(), sm, sk, tstride, M, Mpad, Kv, Kp // cpu, ntaps, 0)
+            tables[group] += struct.pack("<QQqqqQiiiiii", w.data_ptr() + 4 * soff, dst.data_ptr(), sm, sk, tstride, 0, M, Mpad, Kv, Kp // cpu, ntaps, 0)
             counts[group] += 1
         plan = {"ptrs": ptrs, "images": images, "counts": counts}
         for g in ("fwd", "bwd"):
@@ -932,9 +937,141 @@ class Engine:
         self._red_buf = None
         return flat, views
 
+    # ------------------------------------------------------------------ inference schedule (UResNet, eval mode)
+    # SURVEY.md section 8d, k = 1: eval-mode BatchNorm is a fixed per-channel affine, so it is folded into the packed
+    # weights (scale) and the conv bias; ReLU and the residual add run in the conv epilogue (ubr_conv_desc.act).  Every
+    # tensor is written once, activated, and read by its consumers with no transform; block tails, BatchNorm finalize
+    # launches and the raw conv2 / bypass outputs of the training schedule disappear (201 M instead of 250 M elements
+    # per 512x512 image).  Reference call sites: deploy/run_ubresnet_precropped.py:88-89,147 (model.eval(); forward).
+    def _infer_plan(self, dt, device):
+        import struct
+        m = self.model
+        key = ("inf", dt, device)
+        ptrs = tuple(p.data_ptr() for _, p in self.grad_order) + tuple(b.data_ptr() for b in m.buffers())
+        plan = self._plans.get(key)
+        if plan is not None and plan["ptrs"] == ptrs:
+            return plan
+        cpu = L.chans_per_unit(dt)
+        pairs = [(m.conv1, m.bn1), (m.conv10, m.bn10)]
+        for mod in m.modules():
+            if hasattr(mod, "bn2") and hasattr(mod, "conv2"):          # BasicBlock
+                pairs += [(mod.conv1, mod.bn1), (mod.conv2, mod.bn2)]
+                if mod.bypass is not None:
+                    pairs.append((mod.bypass, mod.bnpass))
+        total = sum(bn.num_features for _, bn in pairs)
+        vec = torch.empty(2 * total, dtype=torch.float32, device=device)
+        scale_of, bias_of, fold_tbl, off = {}, {}, b"", 0
+        for conv, bn in pairs:
+            Cn = bn.num_features
+            sc, bi = vec[off:off + Cn], vec[total + off:total + off + Cn]
+            off += Cn
+            scale_of[id(conv.weight)], bias_of[id(bn)] = sc, bi
+            for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var):
+                if t is None or t.dtype != torch.float32 or t.device != device:
+                    raise RuntimeError("ubresnet_amd: inference needs affine BatchNorm2d with float32 running statistics on %s" % device)
+            fold_tbl += struct.pack("<QQQQQQQif", bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                                    conv.bias.data_ptr() if conv.bias is not None else 0, sc.data_ptr(), bi.data_ptr(), Cn, float(bn.eps))
+        images, pack_tbl, n = {}, b"", 0
+        for group, k, w, soff, M, Kv, Kpad, sm, sk, ntaps, tstride in self._plan_items():
+            if group != "fwd":
+                continue
+            if not w.is_contiguous() or w.dtype != torch.float32 or w.device != device:
+                raise RuntimeError("ubresnet_amd: parameters must be contiguous float32 on %s" % device)
+            Mpad = (M + 15) // 16 * 16
+            Kp = Kpad if Kpad is not None else (Kv + cpu - 1) // cpu * cpu
+            dst = torch.empty((ntaps, Kp // cpu, Mpad, cpu), dtype=dt, device=device)
+            images[k] = dst
+            sc = scale_of.get(id(w))
+            pack_tbl += struct.pack("<QQqqqQiiiiii", w.data_ptr() + 4 * soff, dst.data_ptr(), sm, sk, tstride,
+                                    sc.data_ptr() if sc is not None else 0, M, Mpad, Kv, Kp // cpu, ntaps, 0)
+            n += 1
+        dev_tbl = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(device)
+        plan = {"ptrs": ptrs, "images": images, "bias": bias_of, "vec": vec, "fold": dev_tbl(fold_tbl), "nfold": len(pairs),
+                "pack": dev_tbl(pack_tbl), "npack": n}
+        self._plans[key] = plan
+        return plan
+
+    def _block_infer(self, blk, x, out, img, fb, dt):
+        """BasicBlock.forward (models/common_layers.py:39-58) with folded BatchNorms: 2 launches (3 with a bypass conv)"""
+        N, OH, OW, Cout = out.shape
+        S = blk.stride
+        c1 = torch.empty((N, OH, OW, Cout), dtype=dt, device=x.device)
+        ops.conv(x, img[(id(blk.conv1.weight), "fwd")], c1, T3, Cout, S=S, bias=fb[id(blk.bn1)], act=1)
+        sc = x
+        if blk.bypass is not None:
+            sc = torch.empty((N, OH, OW, Cout), dtype=dt, device=x.device)
+            ops.conv(x, img[(id(blk.bypass.weight), "fwd")], sc, T1, Cout, S=S, bias=fb[id(blk.bnpass)])
+        ops.conv(c1, img[(id(blk.conv2.weight), "fwd")], out, T3, Cout, bias=fb[id(blk.bn2)], addend=sc, act=3)
+
+    def _double_infer(self, dbl, x, out, img, fb, dt):
+        mid = torch.empty(out.shape, dtype=dt, device=x.device)
+        self._block_infer(dbl.res1, x, mid, img, fb, dt)
+        self._block_infer(dbl.res2, mid, out, img, fb, dt)
+
+    def _declayer_infer(self, dl, x, cat, Cd, out, img, fb, dt):
+        wp = img[(id(dl.deconv.weight), "tfwd")]
+        up = cat[..., :Cd]
+        for ry in range(2):
+            for rx in range(2):
+                ops.conv(x, wp, _phase(up, ry, rx), ops.transposed_phase_taps(4, 1, 1, 2, ry, rx), Cd)
+        self._double_infer(dl.res, cat, out, img, fb, dt)
+
+    def uresnet_infer(self, x, dt):
+        """eval-mode UResNet.forward (models/ub_uresnet.py:88-147), nothing saved"""
+        m = self.model
+        x = self._check_input(x, m.conv1.in_channels)
+        N, Cin, H, W = x.shape
+        dev, ip = x.device, m.inplanes
+        plan = self._infer_plan(dt, dev)
+        st = L.stream_ptr()
+        L.check(L.lib().ubr_bn_fold_batched(plan["fold"].data_ptr(), plan["nfold"], st), "bn_fold_batched")
+        L.check(L.lib().ubr_pack_weights_batched(L.dtype_id(dt), plan["pack"].data_ptr(), plan["npack"], st), "pack_weights_batched")
+        img, fb = plan["images"], plan["bias"]
+        E = lambda *shape: torch.empty(shape, dtype=dt, device=dev)
+        # stem: conv1 (+bn1 folded, ReLU in the epilogue) writes x0 straight into dec1's concat buffer; pool reads it
+        cat1 = E(N, H, W, 2 * ip)
+        x0 = cat1[..., ip:]
+        x16 = E(N, H, W, 16 * Cin)
+        ops.stem_expand(x, x16)
+        for ci in range(Cin):
+            ops.conv(x16[..., 16 * ci:16 * ci + 16], img[(id(m.conv1.weight), "stem%d" % ci)], x0, self.STEM_TAPS, ip,
+                     bias=fb[id(m.bn1)] if ci == 0 else None, addend=x0 if ci > 0 else None, act=2 if ci == Cin - 1 else 0)
+        p0 = E(N, H // 2, W // 2, ip)
+        ops.maxpool_fwd(x0, None, p0, None, 2)
+        cat2 = E(N, H // 2, W // 2, 4 * ip)
+        cat3 = E(N, H // 4, W // 4, 8 * ip)
+        cat4 = E(N, H // 8, W // 8, 16 * ip)
+        cat5 = E(N, H // 16, W // 16, 32 * ip)
+        x5 = E(N, H // 32, W // 32, 32 * ip)
+        x1, x2, x3, x4 = cat2[..., 2 * ip:], cat3[..., 4 * ip:], cat4[..., 8 * ip:], cat5[..., 16 * ip:]
+        self._double_infer(m.enc_layer1, p0, x1, img, fb, dt)
+        self._double_infer(m.enc_layer2, x1, x2, img, fb, dt)
+        self._double_infer(m.enc_layer3, x2, x3, img, fb, dt)
+        self._double_infer(m.enc_layer4, x3, x4, img, fb, dt)
+        self._double_infer(m.enc_layer5, x4, x5, img, fb, dt)
+        d5o = E(N, H // 16, W // 16, 16 * ip)
+        self._declayer_infer(m.dec_layer5, x5, cat5, 16 * ip, d5o, img, fb, dt)
+        d4o = E(N, H // 8, W // 8, 8 * ip)
+        self._declayer_infer(m.dec_layer4, d5o, cat4, 8 * ip, d4o, img, fb, dt)
+        d3o = E(N, H // 4, W // 4, 4 * ip)
+        self._declayer_infer(m.dec_layer3, d4o, cat3, 4 * ip, d3o, img, fb, dt)
+        d2o = E(N, H // 2, W // 2, 2 * ip)
+        self._declayer_infer(m.dec_layer2, d3o, cat2, 2 * ip, d2o, img, fb, dt)
+        d1o = E(N, H, W, ip)
+        self._declayer_infer(m.dec_layer1, d2o, cat1, ip, d1o, img, fb, dt)
+        nk = m.conv10.out_channels
+        c10 = E(N, H, W, nk)
+        ops.conv(d1o, img[(id(m.conv10.weight), "fwd")], c10, T7, nk, bias=fb[id(m.bn10)], act=1)
+        ncls = m.conv11.out_channels
+        out = torch.empty((N, ncls, H, W), dtype=torch.float32, device=dev)
+        ops.conv(c10, img[(id(m.conv11.weight), "fwd")], out, T7, ncls, bias=m.conv11.bias, logsoftmax=True)
+        return out
+
     # ------------------------------------------------------------------ dispatch
     def forward(self, x, training, dt, save):
         if self.kind == "uresnet":
+            if not training and not save and _INFER_FOLD:
+                return self.uresnet_infer(x, dt), None
             return self.uresnet_forward(x, training, dt, save)
         if self.kind == "aspp":
             return self.aspp_forward(x, training, dt, save)

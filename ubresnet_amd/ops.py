@@ -181,7 +181,7 @@ def _tap_arrays(taps):
 @_timed("conv")
 def conv(x: torch.Tensor, wp: torch.Tensor, y: torch.Tensor, taps, Cout: int, S: int = 1, iy0: int = 0, ix0: int = 0,
          xf: Optional[Affine] = None, bias: Optional[torch.Tensor] = None, addend: Optional[torch.Tensor] = None,
-         stats: Optional[torch.Tensor] = None, logsoftmax: bool = False, tile_hint: int = 0, in_hw=None):
+         stats: Optional[torch.Tensor] = None, logsoftmax: bool = False, tile_hint: int = 0, in_hw=None, act: int = 0):
     """One ubr_conv launch.  x: NHWC input view; y: NHWC output-grid view (or, with logsoftmax, the
     contiguous fp32 NCHW result); taps: [(dy,dx,packed tap index)]."""
     d = L.ConvDesc()
@@ -228,6 +228,7 @@ def conv(x: torch.Tensor, wp: torch.Tensor, y: torch.Tensor, taps, Cout: int, S:
     if xf is not None:
         assert xf.scale.numel() >= Cin
     d.tile_hint = tile_hint
+    d.act = act
     L.check(L.lib().ubr_conv(C.byref(d), L.stream_ptr()), "conv")
 
 
