@@ -307,6 +307,36 @@ int ubr_crop_tiles(const float* view /*[P][rows][cols]*/, int P, int rows, int c
 int ubr_stitch_tiles(const float* scores /*[ntiles][C][th][tw]*/, int C, int th, int tw, const int32_t* tile_desc_host, int ntiles,
                      float* out /*[P][C][rows][cols]*/, int P, int rows, int cols, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Launch plans ("tapes").  The reference has no scheduler of its own: each layer is a Python-level torch.nn call
+ * (models/ub_uresnet.py:88-147) and autograd replays them in reverse.  Here the host records the launch sequence of a
+ * pass ONCE per (network, shape, dtype) and replays it from C++:
+ *   ubr_tape_begin(t, n, streams): from now on every entry point of this header called on this thread with one of the
+ *       `streams` (slot i = streams[i]) still runs AND is appended to the tape with all its arguments resolved
+ *       (descriptor validation, tile selection and LDS planning are not repeated at replay).
+ *   ubr_tape_fork(t, a, b): slot b waits for everything recorded so far on slot a (event record + stream wait);
+ *       this is how the weight-gradient side stream forks from and joins the dgrad chain.
+ *   ubr_tape_mark(t, s) -> id: an event recorded on slot s at this point of every replay; ubr_tape_wait_mark makes any
+ *       other stream (e.g. the RCCL exchange stream of the data-parallel reducer) wait for it.
+ *   ubr_tape_pause(t, 1/0): launches in between run but are not recorded (ops whose operands change per step).
+ *   ubr_tape_replay(t, n, streams): re-issue the recording on the given streams.  All device addresses are baked in,
+ *       so the caller keeps every buffer of the pass alive and at the same address for the life of the tape.
+ * The optimizer steps are never recorded (their scalars change every step).  Not thread-safe per tape; recording is
+ * per thread.
+ * ---------------------------------------------------------------------------------------- */
+#define UBR_TAPE_MAX_STREAMS 4
+typedef struct ubr_tape ubr_tape;
+ubr_tape* ubr_tape_create(void);
+void ubr_tape_destroy(ubr_tape* t);
+int ubr_tape_begin(ubr_tape* t, int nstreams, void* const* streams);
+int ubr_tape_end(ubr_tape* t);
+int ubr_tape_pause(ubr_tape* t, int on);
+int ubr_tape_fork(ubr_tape* t, int from_slot, int to_slot);
+int ubr_tape_mark(ubr_tape* t, int slot);                 /* >= 0: mark id; < 0: error */
+int ubr_tape_wait_mark(const ubr_tape* t, int mark, void* stream);
+int ubr_tape_size(const ubr_tape* t);
+int ubr_tape_replay(const ubr_tape* t, int nstreams, void* const* streams);
+
 const char* ubr_last_error(void);
 int ubr_version(void);
 

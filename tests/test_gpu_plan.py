@@ -1,0 +1,125 @@
+"""Launch plans (ubresnet_amd/plan.py, ubr_tape_* of include/ubresnet_hip.h): a replayed pass must be bit-identical to the
+Python-scheduled pass it was recorded from -- same kernels, same arguments, same stream structure -- for the train step
+(forward, two-stream backward, optimizer) and for eval inference; and it must step aside whenever replay is not safe."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import uresnet_oracle as O
+from ubresnet_amd import synthetic
+
+if torch.cuda.is_available():
+    from ubresnet_amd import plan
+    from ubresnet_amd.models.ub_uresnet import UResNet
+    from ubresnet_amd.models.ASPP_ResNet import ASPP_ResNet
+    from ubresnet_amd.optim import FlatAdam
+    from ubresnet_amd.training.pixelwise_nllloss import PixelWiseNLLLoss
+
+
+def _make(kind, dt):
+    if kind == "uresnet":
+        sd = O.seeded_state_dict(O.uresnet_schema(3, 1, 16, 16), 42)
+        m = UResNet(3, 1, 16)
+        planes = 1
+    else:
+        sd = O.seeded_state_dict(O.aspp_resnet_schema(3, 3, 16), 44)
+        m = ASPP_ResNet(3, 3, 16, False)
+        planes = 3
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    m.compute_dtype = dt
+    return m, planes
+
+
+def _train(kind, dt, steps, enabled, monkeypatch):
+    monkeypatch.setattr(plan, "ENABLED", enabled)
+    m, planes = _make(kind, dt)
+    opt = FlatAdam(m, lr=1e-3, weight_decay=1e-4)
+    crit = PixelWiseNLLLoss()
+    outs, losses = [], []
+    for i in range(steps):
+        x, lab, wgt = synthetic.make_batch(2, 64, 96, 1000 + 10 * i, planes=planes)
+        out = m(torch.from_numpy(x).cuda())
+        loss = crit(out, torch.from_numpy(lab).cuda(), torch.from_numpy(wgt).cuda())
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        outs.append(out.detach().clone())
+        losses.append(float(loss))
+    torch.cuda.synchronize()
+    eng = m.__dict__["_ubr_engine"]
+    bufs = {k: v.clone() for k, v in m.state_dict().items()}
+    return outs, losses, opt.flat.clone(), bufs, eng
+
+
+@pytest.mark.parametrize("kind,dt", [("uresnet", torch.float32), ("uresnet", torch.bfloat16), ("aspp", torch.bfloat16)])
+def test_replayed_train_steps_equal_python_scheduled_steps(kind, dt, monkeypatch):
+    o1, l1, p1, b1, eng1 = _train(kind, dt, 4, True, monkeypatch)
+    o0, l0, p0, b0, eng0 = _train(kind, dt, 4, False, monkeypatch)
+    assert len(eng1._planned) == 1 and not eng0._planned
+    pl = next(iter(eng1._planned.values()))
+    assert pl.uses == 4 and pl.bwd is not None and pl.fwd.tape.size() > 100 and pl.bwd.tape.size() > 200
+    assert l1 == l0
+    for a, b in zip(o1, o0):
+        assert torch.equal(a, b)
+    assert torch.equal(p1, p0), "parameters differ after 4 steps (1 recorded + 3 replayed)"
+    for k in b0:
+        assert torch.equal(b1[k], b0[k]), k            # incl. BatchNorm running statistics and num_batches_tracked
+
+
+def test_outputs_are_fresh_tensors_and_inputs_are_read_in_place(monkeypatch):
+    monkeypatch.setattr(plan, "ENABLED", True)
+    m, _ = _make("uresnet", torch.float32)
+    crit = PixelWiseNLLLoss()
+    xs = [torch.from_numpy(synthetic.make_batch(1, 64, 64, 1000 + i)[0]).cuda() for i in range(3)]
+    lab = torch.zeros((1, 64, 64), dtype=torch.int64, device="cuda")
+    wgt = torch.ones((1, 64, 64), device="cuda")
+    outs = []
+    for x in xs:
+        out = m(x)
+        crit(out, lab, wgt).backward()
+        m.zero_grad()
+        outs.append(out)
+    assert len({o.data_ptr() for o in outs}) == 3
+    assert not torch.equal(outs[0], outs[1])            # earlier outputs were not overwritten by later passes
+    m.eval()
+    with torch.no_grad():
+        e = [m(x) for x in xs]
+    monkeypatch.setattr(plan, "ENABLED", False)
+    with torch.no_grad():
+        for x, got in zip(xs, e):
+            assert torch.equal(m(x), got)
+
+
+def test_plan_steps_aside_when_replay_is_not_safe(monkeypatch):
+    monkeypatch.setattr(plan, "ENABLED", True)
+    m, _ = _make("uresnet", torch.float32)
+    crit = PixelWiseNLLLoss()
+    x, lab, wgt = [torch.from_numpy(a).cuda() for a in synthetic.make_batch(1, 64, 64, 1000)]
+    x2 = torch.from_numpy(synthetic.make_batch(1, 64, 64, 2000)[0]).cuda()
+
+    def grads():
+        return torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone()
+
+    crit(m(x), lab, wgt).backward(); ga = grads(); m.zero_grad()           # records
+    crit(m(x2), lab, wgt).backward(); gb = grads(); m.zero_grad()          # replays
+    # two forwards before either backward: the second one must not reuse the buffers the first one saved
+    oa, ob = m(x), m(x2)
+    crit(ob, lab, wgt).backward(); g2 = grads(); m.zero_grad()
+    crit(oa, lab, wgt).backward(); g1 = grads(); m.zero_grad()
+    assert torch.equal(g1, ga) and torch.equal(g2, gb)
+    # accumulation into existing .grad tensors (which alias the plan's flat buffer) must add, not overwrite
+    crit(m(x), lab, wgt).backward()
+    crit(m(x2), lab, wgt).backward()
+    assert torch.allclose(grads(), ga + gb, rtol=1e-5, atol=1e-8)
+    m.zero_grad()
+    # replaced parameter storage invalidates the baked addresses: the plan is rebuilt, results unchanged
+    eng = m.__dict__["_ubr_engine"]
+    before = next(iter(eng._planned.values()))
+    with torch.no_grad():
+        m.conv11.weight.data = m.conv11.weight.data.clone()
+    crit(m(x), lab, wgt).backward()
+    assert torch.equal(grads(), ga)
+    assert next(iter(eng._planned.values())) is not before

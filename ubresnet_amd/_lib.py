@@ -90,6 +90,8 @@ SYMBOLS = [
     "ubr_maxpool_fwd", "ubr_maxpool_bwd",
     "ubr_logsoftmax_bwd", "ubr_pixelwise_nll_fwd", "ubr_pixelwise_nll_bwd", "ubr_confusion",
     "ubr_channel_sum", "ubr_cast_f64_to_f32", "ubr_zero", "ubr_adam_step", "ubr_sgd_step", "ubr_crop_tiles", "ubr_stitch_tiles", "ubr_last_error", "ubr_version",
+    "ubr_tape_create", "ubr_tape_destroy", "ubr_tape_begin", "ubr_tape_end", "ubr_tape_pause", "ubr_tape_fork", "ubr_tape_mark",
+    "ubr_tape_wait_mark", "ubr_tape_size", "ubr_tape_replay",
 ]
 
 _lib = None
@@ -139,9 +141,22 @@ def _declare(lib):
     lib.ubr_sgd_step.argtypes = [vp, vp, vp, i64, f32, f32, f32, f32, i32, i32, f32, vp]
     lib.ubr_crop_tiles.argtypes = [vp, i32, i32, i32, C.POINTER(C.c_int32), i32, i32, i32, vp, vp]
     lib.ubr_stitch_tiles.argtypes = [vp, i32, i32, i32, C.POINTER(C.c_int32), i32, vp, i32, i32, i32, vp]
+    lib.ubr_tape_create.argtypes = []
+    lib.ubr_tape_create.restype = vp
+    lib.ubr_tape_destroy.argtypes = [vp]
+    lib.ubr_tape_destroy.restype = None
+    lib.ubr_tape_begin.argtypes = [vp, i32, C.POINTER(vp)]
+    lib.ubr_tape_end.argtypes = [vp]
+    lib.ubr_tape_pause.argtypes = [vp, i32]
+    lib.ubr_tape_fork.argtypes = [vp, i32, i32]
+    lib.ubr_tape_mark.argtypes = [vp, i32]
+    lib.ubr_tape_wait_mark.argtypes = [vp, i32, vp]
+    lib.ubr_tape_size.argtypes = [vp]
+    lib.ubr_tape_replay.argtypes = [vp, i32, C.POINTER(vp)]
     for name in SYMBOLS:
         fn = getattr(lib, name)
-        if name not in ("ubr_last_error", "ubr_version", "ubr_stem_wgrad_workspace", "ubr_conv_last_config", "ubr_wgrad_last_config"):
+        if name not in ("ubr_last_error", "ubr_version", "ubr_stem_wgrad_workspace", "ubr_conv_last_config", "ubr_wgrad_last_config",
+                        "ubr_tape_create", "ubr_tape_destroy"):
             fn.restype = C.c_int
 
 

@@ -48,7 +48,7 @@ class _NetFn(torch.autograd.Function):
             pending = getattr(ctx.model, "_grad_accum_pending", None)
             if pending is not None:
                 pending()
-        flat, views = ctx.eng.backward(ctx.sv, g_out, hook)
+        flat, views = ctx.eng.backward(ctx.sv, g_out, hook, allow_plan=not accumulating)
         ctx.sv = None
         # Parameter gradients are installed directly as views of the flat buffer (zero copy, and the
         # data-parallel all-reduce of `flat` IS the all-reduce of every .grad).  Handing them to autograd's

@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libubresnet_hip.so")
-SOURCES = ["ubr_conv.hip", "ubr_wgrad.hip", "ubr_elem.hip", "ubr_head.hip"]
+SOURCES = ["ubr_conv.hip", "ubr_wgrad.hip", "ubr_elem.hip", "ubr_head.hip", "ubr_tape.hip"]
 HEADERS = ["ubr_common.h", "ubr_host.h", os.path.join("..", "..", "include", "ubresnet_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",

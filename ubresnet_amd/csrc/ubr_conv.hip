@@ -433,7 +433,7 @@ int launch_one(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
       maxset = lds;
     }
   }
-  hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, k);
+  ubr_launch(fn, grid, dim3(256), lds, st, k);
   UBR_LAUNCH_CHECK("ubr_conv");
   return UBR_OK;
 }
@@ -744,7 +744,7 @@ __global__ void bn_fold_batched_kernel(const ubr_bn_fold_item* items) {
 
 extern "C" int ubr_bn_fold_batched(const ubr_bn_fold_item* items_dev, int nitems, void* stream) {
   UBR_CHECK(items_dev != nullptr && nitems >= 1 && nitems <= 65535, "ubr_bn_fold_batched: bad arguments");
-  hipLaunchKernelGGL(bn_fold_batched_kernel, dim3(4, (unsigned)nitems), dim3(256), 0, (hipStream_t)stream, items_dev);
+  ubr_launch(bn_fold_batched_kernel, dim3(4, (unsigned)nitems), dim3(256), 0, (hipStream_t)stream, items_dev);
   UBR_LAUNCH_CHECK("ubr_bn_fold_batched");
   return UBR_OK;
 }
@@ -754,9 +754,9 @@ extern "C" int ubr_pack_weights_batched(int dtype, const ubr_pack_item* items_de
   UBR_CHECK(items_dev != nullptr && nitems >= 1 && nitems <= 65535, "ubr_pack_weights_batched: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(48, (unsigned)nitems);
-  if (dtype == UBR_F32) hipLaunchKernelGGL(pack_batched_kernel<float>, grid, dim3(256), 0, st, items_dev);
-  else if (dtype == UBR_BF16) hipLaunchKernelGGL(pack_batched_kernel<bf16_t>, grid, dim3(256), 0, st, items_dev);
-  else hipLaunchKernelGGL(pack_batched_kernel<f16_t>, grid, dim3(256), 0, st, items_dev);
+  if (dtype == UBR_F32) ubr_launch(pack_batched_kernel<float>, grid, dim3(256), 0, st, items_dev);
+  else if (dtype == UBR_BF16) ubr_launch(pack_batched_kernel<bf16_t>, grid, dim3(256), 0, st, items_dev);
+  else ubr_launch(pack_batched_kernel<f16_t>, grid, dim3(256), 0, st, items_dev);
   UBR_LAUNCH_CHECK("ubr_pack_weights_batched");
   return UBR_OK;
 }
@@ -778,9 +778,9 @@ extern "C" int ubr_pack_weights(int dtype, const float* src, void* dst, int M, i
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == UBR_F32) hipLaunchKernelGGL(pack_kernel<float>, dim3(blocks), dim3(256), 0, st, k);
-  else if (dtype == UBR_BF16) hipLaunchKernelGGL(pack_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, k);
-  else hipLaunchKernelGGL(pack_kernel<f16_t>, dim3(blocks), dim3(256), 0, st, k);
+  if (dtype == UBR_F32) ubr_launch(pack_kernel<float>, dim3(blocks), dim3(256), 0, st, k);
+  else if (dtype == UBR_BF16) ubr_launch(pack_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, k);
+  else ubr_launch(pack_kernel<f16_t>, dim3(blocks), dim3(256), 0, st, k);
   UBR_LAUNCH_CHECK("ubr_pack_weights");
   return UBR_OK;
 }

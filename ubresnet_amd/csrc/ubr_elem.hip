@@ -589,7 +589,7 @@ extern "C" int ubr_block_tail_fwd(int dtype, int64_t npix, int C, const void* c2
   UBR_CHECK(mean2 && scale2 && shift2 && ((scale_b == nullptr) == (shift_b == nullptr)) && ((scale_b == nullptr) == (mean_b == nullptr)), "ubr_block_tail_fwd: bad affine pointers");
   const int CU = C / ubr_cpu(dtype);
   const int blocks = pick_blocks(npix, CU);
-  UBR_DT_SWITCH(dtype, hipLaunchKernelGGL(tail_fwd_kernel<TT>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (long)npix, CU, c2, (long)c2_ps,
+  UBR_DT_SWITCH(dtype, ubr_launch(tail_fwd_kernel<TT>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (long)npix, CU, c2, (long)c2_ps,
                                           mean2, scale2, shift2, sc, (long)sc_ps, mean_b, scale_b, shift_b, out, (long)out_ps));
   UBR_LAUNCH_CHECK("ubr_block_tail_fwd");
   return UBR_OK;
@@ -626,8 +626,8 @@ static int tail_bwd_common(bool apply, int dtype, int64_t npix, int C, const voi
   k.red2 = red2; k.redb = red_b; k.g_c2 = g_c2; k.g_sc = g_sc; k.g_c2_ps = g_c2_ps; k.g_sc_ps = g_sc_ps;
   const int blocks = pick_blocks(npix, k.CU, apply ? 2048 : 512);
   const size_t lds = apply ? 0 : (size_t)4 * C * sizeof(double);
-  if (apply) { UBR_DT_SWITCH(dtype, hipLaunchKernelGGL((tail_bwd_kernel<TT, true>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, k)); }
-  else { UBR_DT_SWITCH(dtype, hipLaunchKernelGGL((tail_bwd_kernel<TT, false>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, k)); }
+  if (apply) { UBR_DT_SWITCH(dtype, ubr_launch((tail_bwd_kernel<TT, true>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, k)); }
+  else { UBR_DT_SWITCH(dtype, ubr_launch((tail_bwd_kernel<TT, false>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, k)); }
   UBR_LAUNCH_CHECK(who);
   return UBR_OK;
 }
@@ -670,8 +670,8 @@ static int bn_bwd_common(bool apply, int dtype, int64_t npix, int C, const void*
   k.scale = scale; k.shift = shift; k.mean = mean; k.invstd = invstd; k.k1 = k1; k.k2 = k2; k.red = red; k.gc = gc; k.gc_ps = gc_ps;
   const int blocks = pick_blocks(npix, k.CU, apply ? 2048 : 1024);
   const size_t lds = apply ? 0 : (size_t)2 * C * sizeof(double);
-  if (apply) { UBR_DT_SWITCH(dtype, hipLaunchKernelGGL((bn_bwd_kernel<TT, true>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, k)); }
-  else { UBR_DT_SWITCH(dtype, hipLaunchKernelGGL((bn_bwd_kernel<TT, false>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, k)); }
+  if (apply) { UBR_DT_SWITCH(dtype, ubr_launch((bn_bwd_kernel<TT, true>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, k)); }
+  else { UBR_DT_SWITCH(dtype, ubr_launch((bn_bwd_kernel<TT, false>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, k)); }
   UBR_LAUNCH_CHECK(who);
   return UBR_OK;
 }
@@ -692,7 +692,7 @@ extern "C" int ubr_channel_sum(int dtype, int64_t npix, int C, const void* g, in
   UBR_CHECK(red != nullptr, "ubr_channel_sum: null output");
   const int CU = C / ubr_cpu(dtype);
   const int blocks = pick_blocks(npix, CU, 1024);
-  UBR_DT_SWITCH(dtype, hipLaunchKernelGGL(channel_sum_kernel<TT>, dim3(blocks), dim3(256), (size_t)C * sizeof(double), (hipStream_t)stream,
+  UBR_DT_SWITCH(dtype, ubr_launch(channel_sum_kernel<TT>, dim3(blocks), dim3(256), (size_t)C * sizeof(double), (hipStream_t)stream,
                                           (long)npix, C, CU, g, (long)g_ps, red));
   UBR_LAUNCH_CHECK("ubr_channel_sum");
   return UBR_OK;
@@ -704,7 +704,7 @@ extern "C" int ubr_bn_finalize(const double* stats, double count, const float* g
                                float* scale, float* shift, float* mean, float* invstd, void* stream) {
   UBR_CHECK(stats && gamma && beta && scale && shift && mean && invstd && C > 0 && count >= 1.0, "ubr_bn_finalize: bad arguments");
   UBR_CHECK((running_mean == nullptr) == (running_var == nullptr), "ubr_bn_finalize: running stats must come together");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ubr_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, stats, count, gamma, beta,
+  ubr_launch(bn_finalize_kernel, dim3(ubr_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, stats, count, gamma, beta,
                      running_mean, running_var, (long long*)num_batches_tracked, momentum, eps, C, scale, shift, mean, invstd);
   UBR_LAUNCH_CHECK("ubr_bn_finalize");
   return UBR_OK;
@@ -713,7 +713,7 @@ extern "C" int ubr_bn_eval_affine(const float* gamma, const float* beta, const f
                                   const float* running_var, float eps, int C, float* scale, float* shift,
                                   float* mean, float* invstd, void* stream) {
   UBR_CHECK(gamma && beta && running_mean && running_var && scale && shift && mean && invstd && C > 0, "ubr_bn_eval_affine: bad arguments");
-  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(ubr_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, gamma, beta, running_mean, running_var, eps, C, scale, shift, mean, invstd);
+  ubr_launch(bn_eval_affine_kernel, dim3(ubr_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, gamma, beta, running_mean, running_var, eps, C, scale, shift, mean, invstd);
   UBR_LAUNCH_CHECK("ubr_bn_eval_affine");
   return UBR_OK;
 }
@@ -721,13 +721,13 @@ extern "C" int ubr_bn_bwd_finalize(const double* red, double count, const float*
                                    int C, float* dgamma, float* dbeta, int accumulate, float* k1, float* k2, void* stream) {
   (void)scale; (void)invstd;
   UBR_CHECK(red && k1 && k2 && C > 0 && count >= 1.0, "ubr_bn_bwd_finalize: bad arguments");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ubr_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, red, count, C, dgamma, dbeta, accumulate, k1, k2);
+  ubr_launch(bn_bwd_finalize_kernel, dim3(ubr_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, red, count, C, dgamma, dbeta, accumulate, k1, k2);
   UBR_LAUNCH_CHECK("ubr_bn_bwd_finalize");
   return UBR_OK;
 }
 extern "C" int ubr_cast_f64_to_f32(const double* src, int stride, int slots, float* dst, int n, double scale, int accumulate, void* stream) {
   UBR_CHECK(src && dst && n > 0 && slots >= 1 && stride >= n, "ubr_cast_f64_to_f32: bad arguments");
-  hipLaunchKernelGGL(cast_f64_kernel, dim3(ubr_cdiv(n, 128)), dim3(128), 0, (hipStream_t)stream, src, dst, n, stride, slots, scale, accumulate);
+  ubr_launch(cast_f64_kernel, dim3(ubr_cdiv(n, 128)), dim3(128), 0, (hipStream_t)stream, src, dst, n, stride, slots, scale, accumulate);
   UBR_LAUNCH_CHECK("ubr_cast_f64_to_f32");
   return UBR_OK;
 }
@@ -735,6 +735,11 @@ extern "C" int ubr_zero(void* p, int64_t bytes, void* stream) {
   UBR_CHECK(p != nullptr && bytes > 0, "ubr_zero: bad arguments");
   hipError_t e = hipMemsetAsync(p, 0, (size_t)bytes, (hipStream_t)stream);
   if (e != hipSuccess) { ubr_set_error("ubr_zero: %s", hipGetErrorString(e)); return UBR_ELAUNCH; }
+  ubr_tape* t = ubr_tape_current();
+  if (t != nullptr && t->recording && t->paused == 0) {
+    const size_t nb = (size_t)bytes;
+    t->push((hipStream_t)stream, [p, nb](hipStream_t s) { (void)hipMemsetAsync(p, 0, nb, s); });
+  }
   return UBR_OK;
 }
 
@@ -761,7 +766,7 @@ static int pool_common(bool bwd, int dtype, int N, int H, int W, int C, int stri
     }
     k.pooled = pooled; k.p_ps = p_ps; k.xcopy = xcopy; k.xc_ps = xc_ps;
     const int blocks = pick_blocks(npix_out, k.CU);
-    UBR_DT_SWITCH(dtype, hipLaunchKernelGGL(maxpool_fwd_kernel<TT>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, k));
+    UBR_DT_SWITCH(dtype, ubr_launch(maxpool_fwd_kernel<TT>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, k));
   } else {
     UBR_TRY(check_nhwc(who, dtype, npix_out, C, gp, gp_ps));
     if (ge) UBR_TRY(check_nhwc(who, dtype, npix_in, C, ge, ge_ps));
@@ -769,13 +774,13 @@ static int pool_common(bool bwd, int dtype, int N, int H, int W, int C, int stri
     k.gp = gp; k.gp_ps = gp_ps; k.ge = ge; k.ge_ps = ge_ps; k.gx = gx; k.gx_ps = gx_ps;
     if (amax && stride == 2 && H % 2 == 0 && W % 2 == 0) {
       const int blocks = pick_blocks(npix_out, k.CU);
-      UBR_DT_SWITCH(dtype, hipLaunchKernelGGL(maxpool_bwd_s2_amax_kernel<TT>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, k));
+      UBR_DT_SWITCH(dtype, ubr_launch(maxpool_bwd_s2_amax_kernel<TT>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, k));
     } else if (stride == 2 && H % 2 == 0 && W % 2 == 0) {
       const int blocks = pick_blocks(npix_out, k.CU);
-      UBR_DT_SWITCH(dtype, hipLaunchKernelGGL(maxpool_bwd_s2_kernel<TT>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, k));
+      UBR_DT_SWITCH(dtype, ubr_launch(maxpool_bwd_s2_kernel<TT>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, k));
     } else {
       const int blocks = pick_blocks(npix_in, k.CU);
-      UBR_DT_SWITCH(dtype, hipLaunchKernelGGL(maxpool_bwd_kernel<TT>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, k));
+      UBR_DT_SWITCH(dtype, ubr_launch(maxpool_bwd_kernel<TT>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, k));
     }
   }
   UBR_LAUNCH_CHECK(who);

@@ -324,7 +324,7 @@ extern "C" int ubr_stem_forward(int dtype, const float* x_nchw, int N, int Cin, 
             "ubr_stem_forward: output view must be 16-byte aligned with pixel stride >= Cout");
   const int tiles_x = ubr_cdiv(W, 16), tiles_y = ubr_cdiv(H, 16);
   const size_t lds = ((size_t)Cin * 484 + (size_t)Cin * 49 * Cout + 4 * Cout * 2) * sizeof(float) + 16;
-  UBR_DT_SWITCH(dtype, hipLaunchKernelGGL(stem_fwd_kernel<TT>, dim3(tiles_x * tiles_y * N), dim3(256), lds, (hipStream_t)stream,
+  UBR_DT_SWITCH(dtype, ubr_launch(stem_fwd_kernel<TT>, dim3(tiles_x * tiles_y * N), dim3(256), lds, (hipStream_t)stream,
                                           x_nchw, N, Cin, H, W, weight, bias, Cout, (char*)y.p, (long)y.sn * esz, (long)y.sy * esz,
                                           (long)y.sx * esz, stats, tiles_x, tiles_y));
   UBR_LAUNCH_CHECK("ubr_stem_forward");
@@ -337,7 +337,7 @@ extern "C" int ubr_stem_expand(int dtype, const float* x_nchw, int N, int Cin, i
   UBR_CHECK(ubr_aligned16(out) && out_ps >= 16 * Cin && (out_ps * ubr_esize(dtype)) % 16 == 0, "ubr_stem_expand: output pixel stride must be >= 16*Cin and 16-byte aligned");
   long blocks = ((long)N * Cin * H * W + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  UBR_DT_SWITCH(dtype, hipLaunchKernelGGL(stem_expand_kernel<TT>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x_nchw, N, Cin, H, W,
+  UBR_DT_SWITCH(dtype, ubr_launch(stem_expand_kernel<TT>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x_nchw, N, Cin, H, W,
                                           (char*)out, (long)out_ps));
   UBR_LAUNCH_CHECK("ubr_stem_expand");
   return UBR_OK;
@@ -366,14 +366,14 @@ extern "C" int ubr_stem_wgrad(int dtype, const float* x_nchw, int N, int Cin, in
   const int nwg = stem_wgrad_nwg(N, H, W);
   const size_t lds = ((size_t)256 * Cout + (size_t)Cin * 484) * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
-#define UBR_SW(CO) UBR_DT_SWITCH(dtype, hipLaunchKernelGGL((stem_wgrad_kernel<TT, CO>), dim3(nwg), dim3(256), lds, st, x_nchw, N, Cin, H, W, \
+#define UBR_SW(CO) UBR_DT_SWITCH(dtype, ubr_launch((stem_wgrad_kernel<TT, CO>), dim3(nwg), dim3(256), lds, st, x_nchw, N, Cin, H, W, \
     (const char*)g.p, (long)g.sn * esz, (long)g.sy * esz, (long)g.sx * esz, partial, tiles_x, tiles_y, ntiles))
   if (lds > 64 * 1024) { ubr_set_error("ubr_stem_wgrad: LDS too large"); return UBR_EINVAL; }
   if (Cout == 16) { UBR_SW(16); } else if (Cout == 32) { UBR_SW(32); } else { UBR_SW(64); }
 #undef UBR_SW
   UBR_LAUNCH_CHECK("ubr_stem_wgrad");
   const int nw = Cout * Cin * 49;
-  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(ubr_cdiv(nw + Cout, 256)), dim3(256), 0, st, partial, nwg, nw, Cout, dweight, dbias, accumulate);
+  ubr_launch(stem_wgrad_reduce_kernel, dim3(ubr_cdiv(nw + Cout, 256)), dim3(256), 0, st, partial, nwg, nw, Cout, dweight, dbias, accumulate);
   UBR_LAUNCH_CHECK("ubr_stem_wgrad(reduce)");
   return UBR_OK;
 }
@@ -387,7 +387,7 @@ extern "C" int ubr_logsoftmax_bwd(int dtype, int N, int C, int H, int W, const f
   const long hw = (long)H * W;
   long blocks = ((long)N * hw + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  UBR_DT_SWITCH(dtype, hipLaunchKernelGGL(logsoftmax_bwd_kernel<TT>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, hw, N, C,
+  UBR_DT_SWITCH(dtype, ubr_launch(logsoftmax_bwd_kernel<TT>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, hw, N, C,
                                           g_logp_nchw, logp_nchw, (char*)g_logits, (long)gl_ps));
   UBR_LAUNCH_CHECK("ubr_logsoftmax_bwd");
   return UBR_OK;
@@ -401,7 +401,7 @@ extern "C" int ubr_pixelwise_nll_fwd(const float* predict_nchw, const int64_t* t
   const long hw = (long)H * W;
   long blocks = ((long)N * hw + 255) / 256;
   if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(nll_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, predict_nchw, (const long long*)target,
+  ubr_launch(nll_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, predict_nchw, (const long long*)target,
                      pixelweights, classw, N, C, hw, (long long)ignore_index, acc, bad_labels);
   UBR_LAUNCH_CHECK("ubr_pixelwise_nll_fwd");
   return UBR_OK;
@@ -414,7 +414,7 @@ extern "C" int ubr_pixelwise_nll_bwd(const float* g_loss, const int64_t* target,
   const long hw = (long)H * W;
   long blocks = ((long)N * hw + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(nll_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g_loss, (const long long*)target,
+  ubr_launch(nll_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g_loss, (const long long*)target,
                      pixelweights, classw, N, C, hw, (long long)ignore_index, g_predict_nchw);
   UBR_LAUNCH_CHECK("ubr_pixelwise_nll_bwd");
   return UBR_OK;
@@ -426,7 +426,7 @@ extern "C" int ubr_confusion(const float* logp_nchw, const int64_t* target, int 
   const long hw = (long)H * W;
   long blocks = ((long)N * hw + 255) / 256;
   if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(confusion_kernel, dim3((unsigned)blocks), dim3(256), (size_t)C * C * sizeof(unsigned), (hipStream_t)stream,
+  ubr_launch(confusion_kernel, dim3((unsigned)blocks), dim3(256), (size_t)C * C * sizeof(unsigned), (hipStream_t)stream,
                      logp_nchw, (const long long*)target, N, C, hw, cm);
   UBR_LAUNCH_CHECK("ubr_confusion");
   return UBR_OK;
@@ -487,7 +487,7 @@ extern "C" int ubr_crop_tiles(const float* view, int P, int rows, int cols, cons
   TileK k{};
   int rc = fill_tilek(k, tile_desc_host, ntiles, th, tw, rows, cols, 1, P, false);
   if (rc != UBR_OK) return rc;
-  hipLaunchKernelGGL(crop_tiles_kernel, dim3(ubr_cdiv(th * tw, 256 * 8), ntiles), dim3(256), 0, (hipStream_t)stream, view, out, k);
+  ubr_launch(crop_tiles_kernel, dim3(ubr_cdiv(th * tw, 256 * 8), ntiles), dim3(256), 0, (hipStream_t)stream, view, out, k);
   UBR_LAUNCH_CHECK("ubr_crop_tiles");
   return UBR_OK;
 }
@@ -497,7 +497,7 @@ extern "C" int ubr_stitch_tiles(const float* scores, int C, int th, int tw, cons
   TileK k{};
   int rc = fill_tilek(k, tile_desc_host, ntiles, th, tw, rows, cols, C, P, true);
   if (rc != UBR_OK) return rc;
-  hipLaunchKernelGGL(stitch_tiles_kernel, dim3(ubr_cdiv(C * th * tw, 256 * 8), ntiles), dim3(256), 0, (hipStream_t)stream, scores, out, k);
+  ubr_launch(stitch_tiles_kernel, dim3(ubr_cdiv(C * th * tw, 256 * 8), ntiles), dim3(256), 0, (hipStream_t)stream, scores, out, k);
   UBR_LAUNCH_CHECK("ubr_stitch_tiles");
   return UBR_OK;
 }
@@ -560,7 +560,7 @@ extern "C" int ubr_adam_step(float* param, const float* grad, float* exp_avg, fl
   UBR_CHECK(param && grad && exp_avg && exp_avg_sq && n > 0 && n % 4 == 0 && step >= 1, "ubr_adam_step: bad arguments (n must be a multiple of 4)");
   UBR_CHECK(ubr_aligned16(param) && ubr_aligned16(grad) && ubr_aligned16(exp_avg) && ubr_aligned16(exp_avg_sq), "ubr_adam_step: buffers must be 16-byte aligned");
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-  hipLaunchKernelGGL(adam_kernel, dim3(opt_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, (long)(n / 4),
+  ubr_launch(adam_kernel, dim3(opt_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, (long)(n / 4),
                      lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
   UBR_LAUNCH_CHECK("ubr_adam_step");
   return UBR_OK;
@@ -570,7 +570,7 @@ extern "C" int ubr_sgd_step(float* param, const float* grad, float* momentum_buf
   UBR_CHECK(param && grad && n > 0 && n % 4 == 0, "ubr_sgd_step: bad arguments (n must be a multiple of 4)");
   UBR_CHECK((momentum == 0.f) == (momentum_buf == nullptr), "ubr_sgd_step: momentum buffer iff momentum != 0");
   UBR_CHECK(ubr_aligned16(param) && ubr_aligned16(grad) && (!momentum_buf || ubr_aligned16(momentum_buf)), "ubr_sgd_step: buffers must be 16-byte aligned");
-  hipLaunchKernelGGL(sgd_kernel, dim3(opt_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, param, grad, momentum_buf, (long)(n / 4), lr, momentum,
+  ubr_launch(sgd_kernel, dim3(opt_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, param, grad, momentum_buf, (long)(n / 4), lr, momentum,
                      dampening, weight_decay, nesterov, first_step, grad_scale);
   UBR_LAUNCH_CHECK("ubr_sgd_step");
   return UBR_OK;

@@ -379,7 +379,7 @@ int wlaunch(const WgK& k, const WPlan& p, hipStream_t st) {
       maxset = p.lds;
     }
   }
-  hipLaunchKernelGGL(fn, dim3(p.nsplit, p.gy, p.gz), dim3(256), p.lds, st, k);
+  ubr_launch(fn, dim3(p.nsplit, p.gy, p.gz), dim3(256), p.lds, st, k);
   UBR_LAUNCH_CHECK("ubr_wgrad");
   return UBR_OK;
 }
@@ -513,11 +513,11 @@ extern "C" int ubr_wgrad_reduce(float* slabs, int nsplit, int ntaps, int Cout_pa
   if (nsplit > kRedGroup) {
     // two-level tree keeps every thread's serial chain <= 32 loads (a single pass over 1024 slabs is latency-bound)
     const int groups = ubr_cdiv(nsplit, kRedGroup);
-    hipLaunchKernelGGL(wgrad_reduce_stage1, dim3(blocks, groups), dim3(256), 0, st, slabs, per, nsplit);
+    ubr_launch(wgrad_reduce_stage1, dim3(blocks, groups), dim3(256), 0, st, slabs, per, nsplit);
     UBR_LAUNCH_CHECK("ubr_wgrad_reduce(stage1)");
     k.nsplit = groups; k.slab_stride = per * kRedGroup;
   }
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, k);
+  ubr_launch(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, k);
   UBR_LAUNCH_CHECK("ubr_wgrad_reduce");
   return UBR_OK;
 }

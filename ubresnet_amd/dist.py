@@ -42,6 +42,7 @@ class GradAllReducer:
         self.wait_events = []
         self.use_avg = dist.is_initialized() and dist.get_backend(group) == "nccl"
         self._accum = False
+        self._need_current = True
         model._grad_ready_hook = self._hook
         model._grad_accum_pending = self._begin_accumulate
         if broadcast_init and self.world > 1 and hasattr(model, "parameters"):
@@ -104,12 +105,17 @@ class GradAllReducer:
 
     # called by the executor on the compute stream: flat[lo:hi] is final once the compute stream AND every event in
     # wait_events (work the executor queued on its other streams) have been reached
-    def _hook(self, flat: torch.Tensor, lo: int, hi: int, wait_events=()):
+    def _hook(self, flat: torch.Tensor, lo: int, hi: int, wait_events=(), ordered=True):
+        """ordered=False (replayed launch plans): the whole backward is already queued when the ranges are reported, so
+        the exchange must wait ONLY for `wait_events` (tape marks inside the replayed streams), never for the compute
+        stream's current position -- that would serialise the all-reduce behind the entire backward pass."""
         if self.world == 1 and not self.force:
             return
-        if self.flat is not flat:
+        if self.flat is not flat or lo == 0:
             self.flat, self.pending_lo, self.pending_hi = flat, lo, lo
             self.wait_events = []
+            self._need_current = False
+        self._need_current = self._need_current or ordered
         self.wait_events.extend(wait_events)
         self.pending_hi = hi
         last = hi >= flat.numel()
@@ -127,12 +133,16 @@ class GradAllReducer:
                 # high priority: its own hardware queue (a normal-priority stream can alias the compute stream's queue
                 # and the all-reduce would then serialise with the backward kernels instead of overlapping them)
                 self.stream = torch.cuda.Stream(device=chunk.device, priority=-1)
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(chunk.device))
-            with torch.cuda.stream(self.stream):
+            if self._need_current:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(chunk.device))
                 self.stream.wait_event(ev)
+            with torch.cuda.stream(self.stream):
                 for e in self.wait_events:
-                    self.stream.wait_event(e)
+                    if hasattr(e, "wait_on"):
+                        e.wait_on(self.stream)          # ubresnet_amd.plan.TapeMark
+                    else:
+                        self.stream.wait_event(e)
                 self.wait_events = []
                 self.works.append(dist.all_reduce(chunk, op=op, group=self.group, async_op=True))
         else:

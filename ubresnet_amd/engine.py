@@ -67,6 +67,9 @@ class Engine:
         self._evs, self._ev_next, self._main = [], 0, None
         self._red_buf, self._red_off, self._red_elems = None, 0, 0
         self._bwd_packed, self._pack_evs = None, None
+        self._rec = None                      # plan being recorded (ubresnet_amd/plan.py)
+        self._planned: Dict[tuple, object] = {}
+        self.wws.pin = True                   # tapes bake workspace addresses: outgrown slabs stay allocated
         self.bn_sites: List[BNSite] = []
         self._bn_of: Dict[int, BNSite] = {}
         for m in model.modules():
@@ -94,6 +97,34 @@ class Engine:
             t = torch.full((max(n, 2048),), value, dtype=torch.float32, device=device)
             self._const[key] = t
         return t
+
+    def _new(self, shape, dtype=None, device=None):
+        """every per-pass buffer: while a launch plan is being recorded the tensor is pinned to the plan (its device
+        address is baked into the tape, and the caching allocator must not hand the block to anything else)"""
+        t = torch.empty(shape, dtype=dtype, device=device)
+        if self._rec is not None:
+            self._rec.keep.append(t)
+        return t
+
+    @staticmethod
+    def _fresh(shape, dtype=None, device=None):
+        """tensors handed to the caller (the log-probabilities): new memory on every pass, planned or not"""
+        return torch.empty(shape, dtype=dtype, device=device)
+
+    def _untaped(self, fn):
+        """ops whose operands are not owned by the plan (the caller's image, the loss gradient, the fresh output):
+        run now, stay off the tape; a replayed pass calls them from Python around the replay"""
+        if self._rec is None:
+            return fn()
+        self._rec.tape.pause()
+        try:
+            return fn()
+        finally:
+            self._rec.tape.resume()
+
+    def _fork(self, a, b):
+        if self._rec is not None and self._rec.nstreams > 1:
+            self._rec.tape.fork(a, b)
 
     def relu_affine(self, site: BNSite) -> Affine:
         return Affine(site.mean, site.scale, site.shift, self.const(site.scale.device, 0.0, site.C))
@@ -152,7 +183,7 @@ class Engine:
                 raise RuntimeError("ubresnet_amd: parameters must be contiguous float32 on %s" % device)
             Mpad = (M + 15) // 16 * 16
             Kp = Kpad if Kpad is not None else (Kv + cpu - 1) // cpu * cpu
-            dst = torch.empty((ntaps, Kp // cpu, Mpad, cpu), dtype=dt, device=device)
+            dst = self._new((ntaps, Kp // cpu, Mpad, cpu), dtype=dt, device=device)
             images[k] = dst
             tables[group] += struct.pack("<QQqqqQiiiiii", w.data_ptr() + 4 * soff, dst.data_ptr(), sm, sk, tstride, 0, M, Mpad, Kv, Kp // cpu, ntaps, 0)
             counts[group] += 1
@@ -183,6 +214,7 @@ class Engine:
         e0, e1 = self._pack_evs
         e0.record(torch.cuda.current_stream(dev))      # weights are final and every earlier reader of the images is queued
         self.side.wait_event(e0)
+        self._fork(0, 1)
         self.pack_all(dt, dev, "bwd", stream=self.side)
         e1.record(self.side)
         self._bwd_packed = (dt, dev)
@@ -190,6 +222,7 @@ class Engine:
     def _pack_bwd(self, dt, dev):
         if self._bwd_packed == (dt, dev):
             torch.cuda.current_stream(dev).wait_event(self._pack_evs[1])
+            self._fork(1, 0)
             self._bwd_packed = None
             self._images = self._pack_plan(dt, dev)["images"]
         else:
@@ -204,7 +237,7 @@ class Engine:
 
     def _alloc_pass_workspaces(self, sv: Saved, device, training: bool):
         nf = sum(4 * s.C for s in self.bn_sites)
-        sv.fws = torch.empty(nf, dtype=torch.float32, device=device)
+        sv.fws = self._new(nf, dtype=torch.float32, device=device)
         off = 0
         for s in self.bn_sites:
             s.scale = sv.fws[off:off + s.C]; off += s.C
@@ -215,7 +248,7 @@ class Engine:
         if training:
             NS = L.STAT_SLOTS
             nd = sum(2 * s.C for s in self.bn_sites) * NS
-            sv.dws = torch.empty(nd, dtype=torch.float64, device=device)
+            sv.dws = self._new(nd, dtype=torch.float64, device=device)
             ops.zero_(sv.dws)
             off = 0
             for s in self.bn_sites:
@@ -253,16 +286,16 @@ class Engine:
         dev = x.device
         bn1, bn2 = self.bn(blk.bn1), self.bn(blk.bn2)
         cnt = N * OH * OW
-        c1 = torch.empty((N, OH, OW, Cout), dtype=dt, device=dev)
+        c1 = self._new((N, OH, OW, Cout), dtype=dt, device=dev)
         ops.conv(x, self.packed(blk.conv1.weight, dt, "fwd"), c1, T3, Cout, S=S, xf=xf_in, stats=bn1.stats)
         self._finish_bn(bn1, cnt, training)
-        c2 = torch.empty((N, OH, OW, Cout), dtype=dt, device=dev)
+        c2 = self._new((N, OH, OW, Cout), dtype=dt, device=dev)
         ops.conv(c1, self.packed(blk.conv2.weight, dt, "fwd"), c2, T3, Cout, xf=self.relu_affine(bn1), stats=bn2.stats)
         self._finish_bn(bn2, cnt, training)
         cb = None
         if blk.bypass is not None:
             bnb = self.bn(blk.bnpass)
-            cb = torch.empty((N, OH, OW, Cout), dtype=dt, device=dev)
+            cb = self._new((N, OH, OW, Cout), dtype=dt, device=dev)
             ops.conv(x, self.packed(blk.bypass.weight, dt, "fwd"), cb, T1, Cout, S=S, xf=xf_in, stats=bnb.stats)
             self._finish_bn(bnb, cnt, training)
             ops.block_tail_fwd(c2, bn2.mean, bn2.scale, bn2.shift, cb, bnb.mean, bnb.scale, bnb.shift, out)
@@ -283,14 +316,17 @@ class Engine:
             for s_ in self.bn_sites:
                 tot += 2 * s_.C * NS
             self._red_elems = 2 * tot + 64 * NS * 8      # BN sites (block tails take 2 sites' worth) + head/stem/bias sums
-        self._red_buf = torch.empty(self._red_elems, dtype=torch.float64, device=dev)
+        self._red_buf = self._new(self._red_elems, dtype=torch.float64, device=dev)
         ops.zero_(self._red_buf)
         self._red_off = 0
 
     def _red(self, n, dev):
         k = L.STAT_SLOTS * n
         if self._red_buf is None or self._red_off + k > self._red_buf.numel() or self._red_buf.device != dev:
-            return ops.stat_buffer(n, dev)           # outside a backward pass, or arena exhausted
+            t = ops.stat_buffer(n, dev)             # outside a backward pass, or arena exhausted
+            if self._rec is not None:
+                self._rec.keep.append(t)
+            return t
         t = self._red_buf[self._red_off:self._red_off + k]
         self._red_off += k
         return t
@@ -326,6 +362,7 @@ class Engine:
     def _side_end(self, dev):
         if self._side_on:
             torch.cuda.current_stream(dev).wait_stream(self.side)
+            self._fork(1, 0)
             self._side_on = False
 
     def _wg(self, x, g, *args, **kw):
@@ -336,6 +373,7 @@ class Engine:
         ev = self._event()
         ev.record(self._main)
         self.side.wait_event(ev)
+        self._fork(0, 1)
         ops.wgrad(x, g, *args, stream=self.side, **kw)
         # the caching allocator must not hand these blocks to later main-stream kernels while the side stream reads them
         x.record_stream(self.side)
@@ -352,10 +390,10 @@ class Engine:
         """backward through a = relu(bn(c)) (or bn only): returns g_c; writes dgamma/dbeta"""
         red = self._red(2 * site.C, c.device)
         ops.bn_bwd_reduce(ga, ga2, c, site.scale, site.shift, site.mean, site.invstd, relu, red)
-        k = torch.empty(2 * site.C, dtype=torch.float32, device=c.device)
+        k = self._new(2 * site.C, dtype=torch.float32, device=c.device)
         k1, k2 = k[:site.C], k[site.C:]
         ops.bn_bwd_finalize(red, cnt, site.C, G(site.mod.weight), G(site.mod.bias), False, k1, k2)
-        gc = torch.empty(c.shape, dtype=c.dtype, device=c.device)
+        gc = self._new(c.shape, dtype=c.dtype, device=c.device)
         ops.bn_bwd_apply(ga, ga2, c, site.scale, site.shift, site.mean, site.invstd, relu, k1, k2, gc)
         return gc
 
@@ -394,19 +432,19 @@ class Engine:
         redb = red[2 * Cout * NS:] if byp else None
         ops.block_tail_bwd_reduce(go, go2, out, c2, bn2.scale, bn2.shift, bn2.mean, bn2.invstd,
                                   cb, bnb.mean if byp else None, bnb.invstd if byp else None, red2, redb)
-        k = torch.empty(4 * Cout, dtype=torch.float32, device=dev)
+        k = self._new(4 * Cout, dtype=torch.float32, device=dev)
         ops.bn_bwd_finalize(red2, cnt, Cout, G(blk.bn2.weight), G(blk.bn2.bias), False, k[:Cout], k[Cout:2 * Cout])
         if byp:
             ops.bn_bwd_finalize(redb, cnt, Cout, G(blk.bnpass.weight), G(blk.bnpass.bias), False, k[2 * Cout:3 * Cout], k[3 * Cout:])
-        g_c2 = torch.empty(c2.shape, dtype=dt, device=dev)
-        g_sc = torch.empty(c2.shape, dtype=dt, device=dev)
+        g_c2 = self._new(c2.shape, dtype=dt, device=dev)
+        g_sc = self._new(c2.shape, dtype=dt, device=dev)
         ops.block_tail_bwd_apply(go, go2, out, c2, bn2.scale, bn2.shift, bn2.mean, bn2.invstd, k[:Cout], k[Cout:2 * Cout],
                                  cb, bnb.scale if byp else None, bnb.mean if byp else None, bnb.invstd if byp else None,
                                  k[2 * Cout:3 * Cout] if byp else None, k[3 * Cout:] if byp else None, g_c2, g_sc)
         # conv2: weight grad (input = relu(bn1(c1)) re-formed on load) and data grad
         kk = 9
         self._wg(c1, g_c2, T3, G(blk.conv2.weight), Cout * kk, kk, Cout, Cout, self.wws, xf=self.relu_affine(bn1))
-        g_a1 = torch.empty(c1.shape, dtype=dt, device=dev)
+        g_a1 = self._new(c1.shape, dtype=dt, device=dev)
         self._conv_dgrad(blk.conv2, g_c2, g_a1, 1)
         del g_c2
         g_c1 = self._bn_bwd(bn1, g_a1, None, c1, True, G, cnt)
@@ -417,7 +455,7 @@ class Engine:
             self._wg(x, g_sc, T1, G(blk.bypass.weight), Cin, 1, Cout, Cin, self.wws, S=S, xf=rec.xf_in)
         if not need_gx:
             return None
-        gx = torch.empty(x.shape, dtype=dt, device=dev)
+        gx = self._new(x.shape, dtype=dt, device=dev)
         if byp:
             self._conv_dgrad(blk.conv1, g_c1, gx, S)
             self._conv_dgrad(blk.bypass, g_sc, gx, S, addend=gx, k=1)
@@ -429,7 +467,7 @@ class Engine:
     def double_fwd(self, dbl, x, out, training, dt, xf_in=None):
         N, H, W, _ = x.shape
         S = dbl.res1.stride
-        mid = torch.empty((N, out.shape[1], out.shape[2], out.shape[3]), dtype=dt, device=x.device)
+        mid = self._new((N, out.shape[1], out.shape[2], out.shape[3]), dtype=dt, device=x.device)
         r1 = self.block_fwd(dbl.res1, x, mid, training, dt, xf_in)
         r2 = self.block_fwd(dbl.res2, mid, out, training, dt)
         return (r1, r2) if self._save else None
@@ -473,7 +511,7 @@ class Engine:
                 taps = ops.transposed_phase_taps(4, 1, 1, 2, ry, rx)
                 self._wg(x, _phase(g_up, ry, rx), taps, dW, 16, Cd * 16, Cd, Cin, self.wws, xf=xf_x)
         # data gradient of the transposed conv = ordinary stride-2 conv over g_up
-        gx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+        gx = self._new(x.shape, dtype=x.dtype, device=x.device)
         wp = self.packed(dl.deconv.weight, x.dtype, "tdgrad")
         ops.conv(g_up, wp, gx, ops.conv_taps(4, 1, 1), Cin, S=2)
         return gx, g_cat
@@ -486,8 +524,10 @@ class Engine:
         expanded to 16 channels per plane (column shifts -3..3), then each plane is a 7-tap vertical conv."""
         N, Cin, H, W = x.shape
         Cout = conv1.out_channels
-        x16 = torch.empty((N, H, W, 16 * Cin), dtype=dt, device=x.device)
-        ops.stem_expand(x, x16)
+        x16 = self._new((N, H, W, 16 * Cin), dtype=dt, device=x.device)
+        self._untaped(lambda: ops.stem_expand(x, x16))
+        if self._rec is not None:
+            self._rec.pre = lambda xx: ops.stem_expand(xx, x16)
         w = conv1.weight
         for ci in range(Cin):
             last = ci == Cin - 1
@@ -512,21 +552,19 @@ class Engine:
         N, H, W, _ = d1o.shape
         bn10 = self.bn(m.bn10)
         nk = m.conv10.out_channels
-        c10 = torch.empty((N, H, W, nk), dtype=dt, device=d1o.device)
+        c10 = self._new((N, H, W, nk), dtype=dt, device=d1o.device)
         ops.conv(d1o, self.packed(m.conv10.weight, dt, "fwd"), c10, T7, nk, bias=m.conv10.bias, stats=bn10.stats)
         self._finish_bn(bn10, N * H * W, training)
         ncls = m.conv11.out_channels
-        out = torch.empty((N, ncls, H, W), dtype=torch.float32, device=d1o.device)
-        ops.conv(c10, self.packed(m.conv11.weight, dt, "fwd"), out, T7, ncls, xf=self.relu_affine(bn10),
-                 bias=m.conv11.bias, logsoftmax=True)
+        out = self._final_logsoftmax(m, c10, self.packed(m.conv11.weight, dt, "fwd"), self.relu_affine(bn10), (N, ncls, H, W))
         return c10, out
 
     def head_bwd(self, m, sv, g_logp, G):
         dt, dev = sv.dt, sv.x.device
         N, ncls, H, W = sv.out.shape
         ip = m.conv10.in_channels
-        g_l = torch.empty((N, H, W, 16), dtype=dt, device=dev)
-        ops.logsoftmax_bwd(g_logp, sv.out, g_l)
+        g_l = self._new((N, H, W, 16), dtype=dt, device=dev)
+        self._logsoftmax_bwd(g_logp, sv.out, g_l)
         bn10 = self.bn(m.bn10)
         nk = m.conv10.out_channels
         self._wg(sv.c10, g_l, T7, G(m.conv11.weight), nk * 49, 49, ncls, nk, self.wws, xf=self.relu_affine(bn10))
@@ -534,7 +572,7 @@ class Engine:
         red = self._red(16 + nk, dev)
         ops.channel_sum(g_l, red[:16 * NS])
         ops.cast_f64_to_f32(red[:16 * NS], G(m.conv11.bias), ncls, stride=16)
-        g_a10 = torch.empty((N, H, W, nk), dtype=dt, device=dev)
+        g_a10 = self._new((N, H, W, nk), dtype=dt, device=dev)
         ops.conv(g_l, self._packed_dgrad_padded(m.conv11.weight, dt), g_a10, DG7, nk)
         del g_l
         g_c10 = self._bn_bwd(bn10, g_a10, None, sv.c10, True, G, N * H * W)
@@ -542,9 +580,26 @@ class Engine:
         self._wg(sv.d1o, g_c10, T7, G(m.conv10.weight), ip * 49, 49, nk, ip, self.wws)
         ops.channel_sum(g_c10, red[16 * NS:])
         ops.cast_f64_to_f32(red[16 * NS:], G(m.conv10.bias), nk)
-        g = torch.empty(sv.d1o.shape, dtype=dt, device=dev)
+        g = self._new(sv.d1o.shape, dtype=dt, device=dev)
         self._conv_dgrad(m.conv10, g_c10, g, 1, k=7)
         return g
+
+    def _final_logsoftmax(self, m, c10, wp, xf, shape):
+        """conv11 + bias + LogSoftmax (models/ub_uresnet.py:64,143) into a NEW fp32 NCHW tensor: the one forward op that is
+        never taped, so callers get fresh memory from every pass"""
+        def head():
+            out = self._fresh(shape, dtype=torch.float32, device=c10.device)
+            ops.conv(c10, wp, out, T7, shape[1], xf=xf, bias=m.conv11.bias, logsoftmax=True)
+            return out
+        if self._rec is not None:
+            self._rec.post = head
+        return self._untaped(head)
+
+    def _logsoftmax_bwd(self, g_logp, out, g_l):
+        """first op of backward; reads the loss gradient and the log-probabilities of THIS pass (caller-owned): never taped"""
+        self._untaped(lambda: ops.logsoftmax_bwd(g_logp, out, g_l))
+        if self._rec is not None:
+            self._rec.pre = lambda g, o: ops.logsoftmax_bwd(g, o, g_l)
 
     def _check_input(self, x, cin):
         L.require_cuda(x, "input")
@@ -558,7 +613,7 @@ class Engine:
         return x if x.is_contiguous() else x.contiguous()
 
     def _grad_views(self, dev):
-        flat = torch.empty(self.grad_numel, dtype=torch.float32, device=dev)
+        flat = self._new(self.grad_numel, dtype=torch.float32, device=dev)
         views = {}
         for name, p in self.grad_order:
             o = self.grad_offsets[name]
@@ -573,10 +628,17 @@ class Engine:
         ids = [id(p) for _, p in self.grad_order]
 
         def stage_done(last_param):
-            if grad_ready is None:
-                return
             i = ids.index(id(last_param))
             hi = self.grad_offsets[self.grad_order[i][0]] + (self.grad_order[i][1].numel() + 3) // 4 * 4
+            if self._rec is not None and hi > done[0]:
+                # a replayed backward hands flat[done:hi] to the data-parallel reducer through these tape events
+                m0 = self._rec.tape.mark(0)
+                m1 = self._rec.tape.mark(1) if (self._side_on and self._rec.nstreams > 1) else None
+                self._rec.stages.append((done[0], hi, m0, m1))
+            if grad_ready is None:
+                if hi > done[0]:
+                    done[0] = hi
+                return
             if hi > done[0]:
                 if self._side_on:
                     # flat[done:hi] is final once BOTH streams reach this point: the consumer is told to wait for the
@@ -603,7 +665,7 @@ class Engine:
             for lo, hi in relu_ranges:
                 tmpl[3, lo:hi].zero_()
             self._const[key] = tmpl
-        arena = torch.empty_like(tmpl)
+        arena = self._new(tmpl.shape, dtype=tmpl.dtype, device=tmpl.device)
         arena.copy_(tmpl)
         sv.arena = arena
         offs, o = [], 0
@@ -624,7 +686,7 @@ class Engine:
         """ASPP.forward + ASPP_post.forward (models/ASPP_ResNet.py:227-263,280-286).  e: encoder output view
         [N,h,w,C]; cpost: destination view of the RAW 1x1 output (its BN+ReLU is folded into consumers)."""
         N, h, w, Cn = e.shape
-        acat = torch.empty((N, h, w, 64 + Cn), dtype=dt, device=e.device)
+        acat = self._new((N, h, w, 64 + Cn), dtype=dt, device=e.device)
         cnt = N * h * w
         for b, (conv, bn, k, dil) in enumerate(layer.branches()):
             site = self.bn(bn)
@@ -654,10 +716,10 @@ class Engine:
         red = self._red(Cn, dev)
         ops.channel_sum(g_cpost, red)
         ops.cast_f64_to_f32(red, G(post.ASPP_conv.bias), Cn)
-        g_acat = torch.empty(acat.shape, dtype=dt, device=dev)
+        g_acat = self._new(acat.shape, dtype=dt, device=dev)
         ops.conv(g_cpost, self.packed(post.ASPP_conv.weight, dt, "dgrad"), g_acat, DG1, 64 + Cn)
         del g_cpost
-        g_e = torch.empty(e.shape, dtype=dt, device=dev)
+        g_e = self._new(e.shape, dtype=dt, device=dev)
         ops.maxpool_bwd(e, None, g_acat[..., 64:], g_base, g_e, 1)
         for b, (conv, bn, k, dil) in enumerate(layer.branches()):
             site = self.bn(bn)
@@ -685,7 +747,7 @@ class Engine:
         self.pack_all(dt, dev, "fwd")
         if save:
             self._pack_bwd_early(dt, dev)
-        E = lambda *shape: torch.empty(shape, dtype=dt, device=dev)
+        E = lambda *shape: self._new(shape, dtype=dt, device=dev)
         C3, C4, C5 = 8 * ip, 16 * ip, 32 * ip
         # affine arena: [acat3 | acat4 | acat5 | cat4 (up,post3,e3) | cat5 (up,post4,e4) | skip5 (post5,e5)]
         sizes = [64 + C3, 64 + C4, 64 + C5, C3 + 2 * C3, C4 + 2 * C4, 2 * C5]
@@ -711,7 +773,7 @@ class Engine:
         self._finish_bn(bn1, N * H * W, training)
         cat1 = E(N, H, W, 2 * ip)
         p0 = E(N, H // 2, W // 2, ip)
-        amax = torch.empty((N, H // 2, W // 2, ip), dtype=torch.uint8, device=dev) if save else None   # window arg-max for the backward
+        amax = self._new((N, H // 2, W // 2, ip), dtype=torch.uint8, device=dev) if save else None   # window arg-max for the backward
         ops.maxpool_fwd(c0, self.relu_affine(bn1), p0, cat1[..., ip:], 2, argmax=amax)
         cat2 = E(N, H // 2, W // 2, 4 * ip)
         cat3 = E(N, H // 4, W // 4, 8 * ip)
@@ -781,7 +843,7 @@ class Engine:
         g = self.double_bwd(r2, g, gc3[..., 4 * ip:], G); stage_done(m.enc_layer2.res1.conv1.weight)
         g = self.double_bwd(r1, g, gc2[..., 2 * ip:], G); stage_done(m.enc_layer1.res1.conv1.weight)
         bn1 = self.bn(m.bn1)
-        g_x0 = torch.empty(sv.c0.shape, dtype=dt, device=dev)
+        g_x0 = self._new(sv.c0.shape, dtype=dt, device=dev)
         ops.maxpool_bwd(sv.c0, self.relu_affine(bn1), g, gc1[..., ip:], g_x0, 2, argmax=sv.amax)
         g_c0 = self._bn_bwd(bn1, g_x0, None, sv.c0, True, G, N * H * W)
         self.stem_bwd(m.conv1, sv.x16, g_c0, G)
@@ -816,7 +878,7 @@ class Engine:
         self.pack_all(dt, dev, "fwd")
         if save:
             self._pack_bwd_early(dt, dev)
-        E = lambda *shape: torch.empty(shape, dtype=dt, device=dev)
+        E = lambda *shape: self._new(shape, dtype=dt, device=dev)
 
         # stem: conv1 -> (bn1 + relu folded into consumers) -> pool ; x0 goes into dec1's concat buffer
         bn1 = self.bn(m.bn1)
@@ -825,7 +887,7 @@ class Engine:
         self._finish_bn(bn1, N * H * W, training)
         cat1 = E(N, H, W, 2 * ip)
         p0 = E(N, H // 2, W // 2, ip)
-        amax = torch.empty((N, H // 2, W // 2, ip), dtype=torch.uint8, device=dev) if save else None   # window arg-max for the backward
+        amax = self._new((N, H // 2, W // 2, ip), dtype=torch.uint8, device=dev) if save else None   # window arg-max for the backward
         ops.maxpool_fwd(c0, self.relu_affine(bn1), p0, cat1[..., ip:], 2, argmax=amax)
 
         # encoder: each level's output is written into the skip half of the matching concat buffer
@@ -859,9 +921,7 @@ class Engine:
         ops.conv(d1o, self.packed(m.conv10.weight, dt, "fwd"), c10, T7, nk, bias=m.conv10.bias, stats=bn10.stats)
         self._finish_bn(bn10, N * H * W, training)
         ncls = m.conv11.out_channels
-        out = torch.empty((N, ncls, H, W), dtype=torch.float32, device=dev)
-        ops.conv(c10, self.packed(m.conv11.weight, dt, "fwd"), out, T7, ncls, xf=self.relu_affine(bn10),
-                 bias=m.conv11.bias, logsoftmax=True)
+        out = self._final_logsoftmax(m, c10, self.packed(m.conv11.weight, dt, "fwd"), self.relu_affine(bn10), (N, ncls, H, W))
         if not save:
             return out, None
         sv.x, sv.x16, sv.c0, sv.cat1, sv.p0, sv.amax = x, x16, c0, cat1, p0, amax
@@ -889,8 +949,8 @@ class Engine:
         if not g_logp.is_contiguous():
             g_logp = g_logp.contiguous()
         # ---- head ----
-        g_l = torch.empty((N, H, W, 16), dtype=dt, device=dev)
-        ops.logsoftmax_bwd(g_logp, sv.out, g_l)
+        g_l = self._new((N, H, W, 16), dtype=dt, device=dev)
+        self._logsoftmax_bwd(g_logp, sv.out, g_l)
         bn10 = self.bn(m.bn10)
         nk = m.conv10.out_channels
         self._wg(sv.c10, g_l, T7, G(m.conv11.weight), nk * 49, 49, ncls, nk, self.wws, xf=self.relu_affine(bn10))
@@ -898,7 +958,7 @@ class Engine:
         red = self._red(16 + nk, dev)
         ops.channel_sum(g_l, red[:16 * NS])
         ops.cast_f64_to_f32(red[:16 * NS], G(m.conv11.bias), ncls, stride=16)
-        g_a10 = torch.empty((N, H, W, nk), dtype=dt, device=dev)
+        g_a10 = self._new((N, H, W, nk), dtype=dt, device=dev)
         # data gradient of conv11: K = the 16 (zero-padded) logit channels
         wp = self._packed_dgrad_padded(m.conv11.weight, dt)
         ops.conv(g_l, wp, g_a10, DG7, nk)
@@ -908,7 +968,7 @@ class Engine:
         self._wg(sv.d1o, g_c10, T7, G(m.conv10.weight), ip * 49, 49, nk, ip, self.wws)
         ops.channel_sum(g_c10, red[16 * NS:])
         ops.cast_f64_to_f32(red[16 * NS:], G(m.conv10.bias), nk)
-        g = torch.empty(sv.d1o.shape, dtype=dt, device=dev)
+        g = self._new(sv.d1o.shape, dtype=dt, device=dev)
         self._conv_dgrad(m.conv10, g_c10, g, 1, k=7)
         del g_c10
         stage_done(m.bn10.bias)
@@ -928,7 +988,7 @@ class Engine:
         g = self.double_bwd(e1, g, gc2[..., 2 * ip:], G); stage_done(m.enc_layer1.res1.conv1.weight)
         # ---- stem ----
         bn1 = self.bn(m.bn1)
-        g_x0 = torch.empty(sv.c0.shape, dtype=dt, device=dev)
+        g_x0 = self._new(sv.c0.shape, dtype=dt, device=dev)
         ops.maxpool_bwd(sv.c0, self.relu_affine(bn1), g, gc1[..., ip:], g_x0, 2, argmax=sv.amax)
         g_c0 = self._bn_bwd(bn1, g_x0, None, sv.c0, True, G, N * H * W)
         self.stem_bwd(m.conv1, sv.x16, g_c0, G)
@@ -959,7 +1019,7 @@ class Engine:
                 if mod.bypass is not None:
                     pairs.append((mod.bypass, mod.bnpass))
         total = sum(bn.num_features for _, bn in pairs)
-        vec = torch.empty(2 * total, dtype=torch.float32, device=device)
+        vec = self._new(2 * total, dtype=torch.float32, device=device)
         scale_of, bias_of, fold_tbl, off = {}, {}, b"", 0
         for conv, bn in pairs:
             Cn = bn.num_features
@@ -979,7 +1039,7 @@ class Engine:
                 raise RuntimeError("ubresnet_amd: parameters must be contiguous float32 on %s" % device)
             Mpad = (M + 15) // 16 * 16
             Kp = Kpad if Kpad is not None else (Kv + cpu - 1) // cpu * cpu
-            dst = torch.empty((ntaps, Kp // cpu, Mpad, cpu), dtype=dt, device=device)
+            dst = self._new((ntaps, Kp // cpu, Mpad, cpu), dtype=dt, device=device)
             images[k] = dst
             sc = scale_of.get(id(w))
             pack_tbl += struct.pack("<QQqqqQiiiiii", w.data_ptr() + 4 * soff, dst.data_ptr(), sm, sk, tstride,
@@ -995,16 +1055,16 @@ class Engine:
         """BasicBlock.forward (models/common_layers.py:39-58) with folded BatchNorms: 2 launches (3 with a bypass conv)"""
         N, OH, OW, Cout = out.shape
         S = blk.stride
-        c1 = torch.empty((N, OH, OW, Cout), dtype=dt, device=x.device)
+        c1 = self._new((N, OH, OW, Cout), dtype=dt, device=x.device)
         ops.conv(x, img[(id(blk.conv1.weight), "fwd")], c1, T3, Cout, S=S, bias=fb[id(blk.bn1)], act=1)
         sc = x
         if blk.bypass is not None:
-            sc = torch.empty((N, OH, OW, Cout), dtype=dt, device=x.device)
+            sc = self._new((N, OH, OW, Cout), dtype=dt, device=x.device)
             ops.conv(x, img[(id(blk.bypass.weight), "fwd")], sc, T1, Cout, S=S, bias=fb[id(blk.bnpass)])
         ops.conv(c1, img[(id(blk.conv2.weight), "fwd")], out, T3, Cout, bias=fb[id(blk.bn2)], addend=sc, act=3)
 
     def _double_infer(self, dbl, x, out, img, fb, dt):
-        mid = torch.empty(out.shape, dtype=dt, device=x.device)
+        mid = self._new(out.shape, dtype=dt, device=x.device)
         self._block_infer(dbl.res1, x, mid, img, fb, dt)
         self._block_infer(dbl.res2, mid, out, img, fb, dt)
 
@@ -1027,12 +1087,14 @@ class Engine:
         L.check(L.lib().ubr_bn_fold_batched(plan["fold"].data_ptr(), plan["nfold"], st), "bn_fold_batched")
         L.check(L.lib().ubr_pack_weights_batched(L.dtype_id(dt), plan["pack"].data_ptr(), plan["npack"], st), "pack_weights_batched")
         img, fb = plan["images"], plan["bias"]
-        E = lambda *shape: torch.empty(shape, dtype=dt, device=dev)
+        E = lambda *shape: self._new(shape, dtype=dt, device=dev)
         # stem: conv1 (+bn1 folded, ReLU in the epilogue) writes x0 straight into dec1's concat buffer; pool reads it
         cat1 = E(N, H, W, 2 * ip)
         x0 = cat1[..., ip:]
         x16 = E(N, H, W, 16 * Cin)
-        ops.stem_expand(x, x16)
+        self._untaped(lambda: ops.stem_expand(x, x16))
+        if self._rec is not None:
+            self._rec.pre = lambda xx: ops.stem_expand(xx, x16)
         for ci in range(Cin):
             ops.conv(x16[..., 16 * ci:16 * ci + 16], img[(id(m.conv1.weight), "stem%d" % ci)], x0, self.STEM_TAPS, ip,
                      bias=fb[id(m.bn1)] if ci == 0 else None, addend=x0 if ci > 0 else None, act=2 if ci == Cin - 1 else 0)
@@ -1063,12 +1125,18 @@ class Engine:
         c10 = E(N, H, W, nk)
         ops.conv(d1o, img[(id(m.conv10.weight), "fwd")], c10, T7, nk, bias=fb[id(m.bn10)], act=1)
         ncls = m.conv11.out_channels
-        out = torch.empty((N, ncls, H, W), dtype=torch.float32, device=dev)
-        ops.conv(c10, img[(id(m.conv11.weight), "fwd")], out, T7, ncls, bias=m.conv11.bias, logsoftmax=True)
-        return out
+        return self._final_logsoftmax(m, c10, img[(id(m.conv11.weight), "fwd")], None, (N, ncls, H, W))
 
     # ------------------------------------------------------------------ dispatch
     def forward(self, x, training, dt, save):
+        from . import plan
+        return plan.forward(self, x, training, dt, save)
+
+    def backward(self, sv, g_out, grad_ready=None, allow_plan=True):
+        from . import plan
+        return plan.backward(self, sv, g_out, grad_ready, allow_plan)
+
+    def forward_eager(self, x, training, dt, save):
         if self.kind == "uresnet":
             if not training and not save and _INFER_FOLD:
                 return self.uresnet_infer(x, dt), None
@@ -1077,7 +1145,7 @@ class Engine:
             return self.aspp_forward(x, training, dt, save)
         raise RuntimeError("ubresnet_amd: unknown network kind %r" % self.kind)
 
-    def backward(self, sv, g_out, grad_ready=None):
+    def backward_eager(self, sv, g_out, grad_ready=None):
         if self.kind == "uresnet":
             return self.uresnet_backward(sv, g_out, grad_ready)
         if self.kind == "aspp":

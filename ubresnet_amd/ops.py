@@ -237,10 +237,14 @@ class WgradWorkspace:
 
     def __init__(self):
         self.buf = None
+        self.pin = False      # launch plans bake the address into their tapes: an outgrown buffer must stay allocated
+        self.old = []
 
     def get(self, nbytes: int, device) -> torch.Tensor:
         n = (nbytes + 3) // 4
         if self.buf is None or self.buf.numel() < n or self.buf.device != device:
+            if self.pin and self.buf is not None:
+                self.old.append(self.buf)
             self.buf = torch.empty(max(n, 1 << 20), dtype=torch.float32, device=device)
         return self.buf
 

@@ -1,0 +1,212 @@
+"""Launch plans: one recorded C++ tape per (network, input shape, dtype, mode) instead of ~560 Python-issued launches.
+
+The reference has no scheduler (each layer is a torch.nn call, models/ub_uresnet.py:88-147; autograd replays them).
+Round 1 of this package scheduled the kernels from Python; that costs 10.6 ms of host time per 13.7 ms train step.
+Here the FIRST pass of a shape runs the ordinary Python schedule (ubresnet_amd/engine.py) while the C library records
+every launch with its resolved arguments (ubr_tape_*, include/ubresnet_hip.h); later passes replay the tape with one
+C call.  What makes that legal:
+
+  * every buffer the pass touches is owned by the plan and stays at its address (``Engine._new`` pins allocations made
+    while recording; with 288 GB of HBM the ~1 GB/image of a bf16 train step is cheap to keep);
+  * the three ops whose operands belong to the caller -- the input image (stem expansion), the fresh log-probability
+    tensor (conv11 + LogSoftmax) and the incoming loss gradient (LogSoftmax backward) -- stay off the tape and are issued
+    from Python around the replay, so inputs are read in place and outputs are new tensors on every call;
+  * the fork/join structure of the two-stream backward and the hand-over points of the data-parallel reducer are tape
+    nodes (events), not Python calls.
+
+A plan is used only when it is safe: same parameter/buffer storage as at record time, no forward pass of the same plan
+still waiting for its backward, no gradient accumulation into existing ``.grad`` tensors, no launch profiler, no stream
+capture.  Everything else takes the ordinary schedule, which stays the reference for the bitwise-equality tests.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+from . import _lib as L
+
+ENABLED = os.environ.get("UBR_PLAN", "1") != "0"
+MAX_PLANS = 4
+
+
+class Tape:
+    def __init__(self):
+        self.h = L.lib().ubr_tape_create()
+        if not self.h:
+            raise RuntimeError("ubresnet_amd: ubr_tape_create failed")
+
+    def __del__(self):
+        try:
+            if self.h:
+                L.lib().ubr_tape_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    @staticmethod
+    def _arr(streams):
+        return (C.c_void_p * len(streams))(*[int(s) for s in streams])
+
+    def begin(self, streams):
+        L.check(L.lib().ubr_tape_begin(self.h, len(streams), self._arr(streams)), "tape_begin")
+
+    def end(self):
+        L.check(L.lib().ubr_tape_end(self.h), "tape_end")
+
+    def pause(self):
+        L.check(L.lib().ubr_tape_pause(self.h, 1), "tape_pause")
+
+    def resume(self):
+        L.check(L.lib().ubr_tape_pause(self.h, 0), "tape_resume")
+
+    def fork(self, a, b):
+        L.check(L.lib().ubr_tape_fork(self.h, a, b), "tape_fork")
+
+    def mark(self, slot) -> int:
+        m = L.lib().ubr_tape_mark(self.h, slot)
+        if m < 0:
+            L.check(m, "tape_mark")
+        return m
+
+    def replay(self, streams):
+        L.check(L.lib().ubr_tape_replay(self.h, len(streams), self._arr(streams)), "tape_replay")
+
+    def size(self) -> int:
+        return L.lib().ubr_tape_size(self.h)
+
+
+class TapeMark:
+    """a point of a replayed stream another stream can wait for (the data-parallel reducer's exchange stream)"""
+    __slots__ = ("tape", "idx")
+
+    def __init__(self, tape, idx):
+        self.tape, self.idx = tape, idx
+
+    def wait_on(self, stream):
+        L.check(L.lib().ubr_tape_wait_mark(self.tape.h, self.idx, stream.cuda_stream), "tape_wait_mark")
+
+
+class Recording:
+    """state of one tape while it records"""
+
+    def __init__(self, nstreams):
+        self.tape = Tape()
+        self.nstreams = nstreams
+        self.keep = []           # every tensor allocated during the pass
+        self.stages = []         # backward: (lo, hi, mark on the compute stream, mark on the side stream or None)
+        self.pre = None          # callable(s) issued from Python before a replay
+        self.post = None         # ... and after it
+
+
+class PlannedPass:
+    def __init__(self, key, sig):
+        self.key, self.sig = key, sig
+        self.fwd = None          # Recording
+        self.bwd = None
+        self.sv = None
+        self.flat = self.views = None
+        self.in_flight = False
+        self.uses = 0
+
+
+def _signature(model):
+    return tuple(t.data_ptr() for t in model.parameters()) + tuple(t.data_ptr() for t in model.buffers())
+
+
+def _streams(eng, dev):
+    main = L.stream_ptr()
+    if eng.side is not None and os.environ.get("UBR_WGRAD_STREAM", "1") != "0":
+        return [main, eng.side.cuda_stream]
+    return [main]
+
+
+def usable(eng, x) -> bool:
+    from . import ops
+    return (ENABLED and eng.kind in ("uresnet", "aspp") and x.is_cuda and ops._prof is None
+            and not torch.cuda.is_current_stream_capturing())
+
+
+def forward(eng, x, training, dt, save):
+    """-> (out, sv) like Engine.forward, through a plan when one applies"""
+    if not usable(eng, x):
+        return eng.forward_eager(x, training, dt, save)
+    dev = x.device
+    if os.environ.get("UBR_WGRAD_STREAM", "1") != "0":
+        eng._ensure_side(dev)
+    key = (tuple(x.shape), dt, bool(training), bool(save), dev.index)
+    sig = _signature(eng.model)
+    plan = eng._planned.get(key)
+    if plan is not None and plan.sig != sig:
+        del eng._planned[key]            # parameter or buffer storage was replaced: the baked addresses are stale
+        plan = None
+    if plan is not None and plan.in_flight:
+        return eng.forward_eager(x, training, dt, save)      # a second forward before the first one's backward
+    streams = _streams(eng, dev)
+    if plan is None:
+        while len(eng._planned) >= MAX_PLANS:                # oldest plan that is not waiting for its backward
+            victims = [k for k, p in eng._planned.items() if not p.in_flight]
+            if not victims:
+                return eng.forward_eager(x, training, dt, save)
+            del eng._planned[min(victims, key=lambda k: eng._planned[k].uses)]
+        plan = PlannedPass(key, sig)
+        rec = Recording(len(streams))
+        eng._rec = rec
+        rec.tape.begin(streams)
+        try:
+            out, sv = eng.forward_eager(x, training, dt, save)
+        finally:
+            eng._rec = None
+            rec.tape.end()
+        plan.fwd, plan.sv = rec, sv
+        eng._planned[key] = plan
+    else:
+        x = eng._check_input(x, eng.model.conv1.in_channels)
+        plan.fwd.pre(x)
+        plan.fwd.tape.replay(streams)
+        out = plan.fwd.post()
+        eng._bwd_packed = None           # (an eager backward after a replayed forward repacks its own weight images)
+        sv = plan.sv
+        if sv is not None:
+            sv.x, sv.out = x, out
+    plan.uses += 1
+    if save:
+        plan.in_flight = True
+        sv.plan = plan
+    return out, sv
+
+
+def backward(eng, sv, g_out, grad_ready, allow_plan=True):
+    plan = getattr(sv, "plan", None)
+    if plan is None or plan.sv is not sv:
+        return eng.backward_eager(sv, g_out, grad_ready)
+    dev = g_out.device
+    try:
+        if not allow_plan or not usable(eng, g_out) or plan.sig != _signature(eng.model):
+            return eng.backward_eager(sv, g_out, grad_ready)
+        streams = _streams(eng, dev)
+        if plan.bwd is None:
+            if len(streams) != plan.fwd.nstreams:
+                return eng.backward_eager(sv, g_out, grad_ready)
+            rec = Recording(len(streams))
+            eng._rec = rec
+            rec.tape.begin(streams)
+            try:
+                flat, views = eng.backward_eager(sv, g_out, grad_ready)
+            finally:
+                eng._rec = None
+                rec.tape.end()
+            plan.bwd, plan.flat, plan.views = rec, flat, views
+            return flat, views
+        if not g_out.is_contiguous():
+            g_out = g_out.contiguous()
+        plan.bwd.pre(g_out, sv.out)
+        plan.bwd.tape.replay(streams)
+        if grad_ready is not None:
+            for lo, hi, m0, m1 in plan.bwd.stages:
+                marks = (TapeMark(plan.bwd.tape, m0),) + ((TapeMark(plan.bwd.tape, m1),) if m1 is not None else ())
+                grad_ready(plan.flat, lo, hi, wait_events=marks, ordered=False)
+        return plan.flat, plan.views
+    finally:
+        plan.in_flight = False
