@@ -39,7 +39,7 @@ struct ConvK {
   int x_sy32, x_sx32;                            // input row / pixel strides in bytes (per-image offsets fit 31 bits)
   int step_j, step_hy, step_goff, wrap_goff;     // halo walk: advance of (column item, row, byte offset) per 256 items
   int wl_off, halo_off, red_off;                 // LDS carve offsets
-  int epilogue, act;
+  int epilogue, act, wide_store, dbg, wlinear, N;
   int8_t dy[UBR_MAX_TAPS], dx[UBR_MAX_TAPS];
   uint8_t wt[UBR_MAX_TAPS];
 };
@@ -405,6 +405,445 @@ __global__ __launch_bounds__(256, ((NT == 4 && FW <= 2 && !PIPE) ? 4 : 2)) void 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Thin layers (one cin block: Cin <= 32 for 16-bit types, stride 1): the full- and half-resolution convolutions that
+// hold 72 % of the network's activation bytes and run on the HBM roofline, not the MFMA one (AI 105-124 flop/B).
+// Same LDS images and MFMA addressing as conv_igemm_kernel; what changes is the ORDER of a workgroup's life, because
+// for these tiles (36 KB of HBM traffic, 40-72 MFMAs per wave) latency chains were the cost, not instructions:
+//   * the halo loads are issued at kernel entry, before any table is built -- the offset / weight-source tables are
+//     computed while they fly;
+//   * the weight slab is loaded into registers right behind them (it used to be a second, serialised round trip
+//     after the halo had been written to LDS);
+//   * the MFMA loop prefetches the next step's tap offset and weight fragments (no LDS read -> address -> LDS read
+//     chain per step);
+//   * 16-bit outputs are stored as one 16-byte store per lane (two pixel fragments exchange half their channels with
+//     v_permlane16_swap) instead of two 8-byte stores: the epilogue was store-issue bound;
+//   * BatchNorm+ReLU on load (XF) is one packed FMA + max per channel pair for 16-bit types,
+//     x*s + (beta - mean*s): the fp32 cancellation error is far below a bf16 ulp (fp32 keeps the (x-mean)*s+beta form);
+//   * <= 128 VGPRs: four workgroups per CU alone, and two beside the 240-VGPR weight-gradient kernels of the side stream
+//     (the 165-VGPR kernel dropped to ONE workgroup per CU there).
+// ---------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ void store_frag_pair(char* p0, char* p1, bool ok0, bool ok1, const float* v0, const float* v1, int q);
+template <> __device__ __forceinline__ void store_frag_pair<float>(char* p0, char* p1, bool ok0, bool ok1, const float* v0, const float* v1, int q) {
+  if (ok0) store4<float>(p0, v0);
+  if (ok1) store4<float>(p1, v1);
+}
+// 16-bit types: lane (q, l16) holds channels 4q..4q+3 of pixel l16 of fragment 0 (X) and of fragment 1 (Y), 8 bytes each.
+// v_permlane16_swap exchanges the odd quads of X with the even quads of Y: afterwards an even quad holds channels
+// 4q..4q+7 of its fragment-0 pixel and an odd quad channels 4(q-1)..4q+3 of its fragment-1 pixel -- 16 contiguous bytes.
+__device__ __forceinline__ void store_pair16(char* p0, char* p1, bool ok0, bool ok1, uint2 X, uint2 Y, int q) {
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 3" : "+v"(X.x), "+v"(Y.x), "+v"(X.y), "+v"(Y.y));
+  const uint4 v = make_uint4(X.x, X.y, Y.x, Y.y);
+  const bool odd = (q & 1) != 0;
+  char* p = odd ? (p1 - 8) : p0;          // p1 addresses channel 4q of fragment 1: an odd quad's 16 bytes start one quad lower
+  if (odd ? ok1 : ok0) *reinterpret_cast<uint4*>(p) = v;
+}
+template <> __device__ __forceinline__ void store_frag_pair<bf16_t>(char* p0, char* p1, bool ok0, bool ok1, const float* v0, const float* v1, int q) {
+  store_pair16(p0, p1, ok0, ok1, make_uint2(ET<bf16_t>::pk2(v0[0], v0[1]), ET<bf16_t>::pk2(v0[2], v0[3])),
+               make_uint2(ET<bf16_t>::pk2(v1[0], v1[1]), ET<bf16_t>::pk2(v1[2], v1[3])), q);
+}
+template <> __device__ __forceinline__ void store_frag_pair<f16_t>(char* p0, char* p1, bool ok0, bool ok1, const float* v0, const float* v1, int q) {
+  f16x4_t a, b;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { a[r] = (_Float16)v0[r]; b[r] = (_Float16)v1[r]; }
+  store_pair16(p0, p1, ok0, ok1, __builtin_bit_cast(uint2, a), __builtin_bit_cast(uint2, b), q);
+}
+
+typedef __attribute__((ext_vector_type(4))) unsigned ubr_u4;
+typedef __attribute__((ext_vector_type(2))) unsigned ubr_u2;
+
+struct ThinK {
+  const char* x; long x_sn; int x_sy, x_sx; unsigned x_bytes;
+  const float *in_sub, *in_scale, *in_shift, *in_lo;
+  const char* w;
+  char* y; long y_sn; int y_sy, y_sx; unsigned y_bytes;
+  const char* ad; long a_sn; int a_sy, a_sx; unsigned a_bytes;
+  const float* bias; double* stats;
+  int H, W, HW, nitems; unsigned hw_magic;
+  int tiles_x, tiles_y, ntiles; unsigned tx_magic, ty_magic;
+  int steps, nunits, hy_org, hx_org, dymin, dxmin;
+  int Cout, Cout_pad, CU, OH, OW;
+  int act, epilogue, wlinear, dbg;
+  int wl_off, halo_off, red_off;
+  int8_t dy[UBR_MAX_TAPS], dx[UBR_MAX_TAPS];
+  uint8_t wt[UBR_MAX_TAPS];
+};
+
+// exact unsigned division of small operands by a runtime divisor: magic = ceil(2^32 / d) for d >= 2 (valid while n * d < 2^32);
+// d == 1 has no 32-bit magic and is encoded as 0
+__device__ __forceinline__ unsigned udiv_magic(unsigned n, unsigned magic) { return magic == 0u ? n : __umulhi(n, magic); }
+
+template <typename T, int FW, int NT, int TWF, int UPB, bool XF, bool LSM>
+__global__ __launch_bounds__(256, 3) void conv_thin_kernel(const ThinK k) {
+  constexpr int TN = NT * 16;
+  constexpr int TH = 4 * FW / TWF;
+  constexpr int TW = TWF * 16;
+  constexpr int CPU = ET<T>::CPU;
+  constexpr int ESZ = 16 / CPU;
+  constexpr int LG = UPB == 4 ? 2 : (UPB == 2 ? 1 : 0);
+  constexpr int PIXB = UPB * 16 + 16;         // LDS bytes per halo pixel (16 bytes of padding: conflict-free fragment reads)
+  constexpr int HS = UPB == 4 ? 6 : 5;        // halo register slots per thread (host: nitems <= 256*HS)
+  constexpr int PPS = 256 / UPB;              // halo pixels covered by one slot of the whole workgroup
+  constexpr int WB = 4;                       // weight items per thread and batch
+  constexpr int FH = 4;                       // pixel fragments per accumulator group
+  static_assert(TWF == 2 && FW % FH == 0, "tile shape");
+  constexpr bool WIDE = ESZ == 2;             // 16-bit outputs: one 16-byte store per lane and fragment pair
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* tbl = reinterpret_cast<int*>(smem);
+  char* wl = smem + k.wl_off;
+  char* halo = smem + k.halo_off;
+  float* red = reinterpret_cast<float*>(smem + k.red_off);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, l16 = lane & 15;
+  const int n0 = blockIdx.y * TN;
+  const int c = tid & (UPB - 1);
+  const int nw = 4 * k.steps * TN;
+
+  // ---- per-thread geometry, computed ONCE (the workgroup is persistent): every halo slot's position inside the halo and
+  // its byte offset relative to the tile origin; per tile a slot then costs an add, a compare and a select ----
+  int hxu[HS], relu[HS];
+  int hyu[XF ? HS : 1];
+#pragma unroll
+  for (int u = 0; u < HS; ++u) {
+    const int pix = (tid >> LG) + u * PPS;
+    const int hy = (int)udiv_magic((unsigned)pix, k.hw_magic), hx = pix - hy * k.HW;
+    const bool in = tid + u * 256 < k.nitems;
+    hxu[u] = in ? hx : -(1 << 24);            // fails every column check: the slot loads zeros
+    relu[u] = hy * k.x_sy + hx * k.x_sx + c * 16;
+    if constexpr (XF) hyu[u] = hy;
+  }
+  char* const halo_w = halo + (tid >> LG) * PIXB + c * 16;
+
+  ubr_u4 hv[HS];
+  unsigned hok = 0u;
+  auto load_halo = [&](int tile) {
+    const unsigned t = (unsigned)__builtin_amdgcn_readfirstlane(tile);
+    const unsigned r = udiv_magic(t, k.tx_magic), tx = t - r * (unsigned)k.tiles_x;
+    const unsigned n = udiv_magic(r, k.ty_magic), ty = r - n * (unsigned)k.tiles_y;
+    const int hy0 = (int)ty * TH + k.hy_org, hx0 = (int)tx * TW + k.hx_org;
+    // rows outside the image fall outside the buffer range (negative offsets wrap to huge unsigned ones) and read as zero;
+    // columns outside it would alias the neighbouring row, so they are checked and sent out of range explicitly
+    __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)(k.x + (long)n * k.x_sn), 0, (int)k.x_bytes, 0x00020000);
+    const int goff = hy0 * k.x_sy + hx0 * k.x_sx;
+    hok = 0u;
+#pragma unroll
+    for (int u = 0; u < HS; ++u) {
+      const bool ok = (unsigned)(hx0 + hxu[u]) < (unsigned)k.W;
+      int vo = ok ? relu[u] + goff : -1;
+      if (k.dbg & 1) vo = -1;
+      hv[u] = __builtin_amdgcn_raw_buffer_load_b128(xr, vo, 0, 0);
+      if constexpr (XF) { if (ok && (unsigned)(hy0 + hyu[u]) < (unsigned)k.H) hok |= 1u << u; }
+    }
+  };
+
+  // ---- prologue: everything with a memory latency is put in flight first ----
+  const int ntiles = k.ntiles;
+  int tile = blockIdx.x;
+  load_halo(tile);
+  // weight slab.  For the natural tap order with one cout tile the slab IS the packed image (unit u = tap*UPB + c at
+  // image item u*TN + nn): a linear copy with no table in front of it.
+  uint4 wv[WB];
+  if (k.wlinear) {
+    const int nvalid = k.nunits * TN;
+#pragma unroll
+    for (int u = 0; u < WB; ++u) {
+      const int i = tid + u * 256;
+      wv[u] = make_uint4(0u, 0u, 0u, 0u);
+      if (i < nvalid) wv[u] = ldg16(k.w + (long)i * 16);
+    }
+  }
+  float bs[NT][4];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ch = n0 + j * 16 + 4 * q + r;
+      bs[j][r] = (k.bias != nullptr && ch < k.Cout) ? k.bias[ch] : 0.f;
+    }
+  // (the same (x - mean)*scale + beta form as every other kernel of the library: an activation re-formed on load by the
+  // forward conv, the weight gradient and the BatchNorm backward must be the SAME bits, whichever kernel or tile computes it)
+  float xsc[XF ? CPU : 1], xsh[XF ? CPU : 1], xlo[XF ? CPU : 1], xsub[XF ? CPU : 1];
+  if constexpr (XF) {
+#pragma unroll
+    for (int e = 0; e < CPU; ++e) {
+      const int ch = c * CPU + e;
+      xsc[e] = k.in_scale[ch]; xlo[e] = k.in_lo[ch]; xsub[e] = k.in_sub[ch]; xsh[e] = k.in_shift[ch];
+    }
+  }
+  int* wsrc = tbl + 4 * k.steps;
+  for (int u = tid; u < 4 * k.steps; u += 256) {
+    int off = 0, v = -1;
+    if (u < k.nunits) {
+      const int tap = u >> LG, cc = u & (UPB - 1);
+      off = ((k.dy[tap] - k.dymin) * k.HW + (k.dx[tap] - k.dxmin)) * PIXB + cc * 16;
+      v = ((int)k.wt[tap] * k.CU + cc) * k.Cout_pad;
+    }
+    tbl[u] = off;
+    wsrc[u] = v;
+  }
+  if (k.wlinear) {
+#pragma unroll
+    for (int u = 0; u < WB; ++u) {
+      const int i = tid + u * 256;
+      if (i < nw) *reinterpret_cast<uint4*>(wl + (long)i * 16) = wv[u];
+    }
+    const int nvalid = k.nunits * TN;
+    for (int ib = tid + 256 * WB; ib < nw; ib += 256 * WB) {       // 49-tap layers only
+#pragma unroll
+      for (int u = 0; u < WB; ++u) {
+        const int i = ib + u * 256;
+        wv[u] = make_uint4(0u, 0u, 0u, 0u);
+        if (i < nvalid) wv[u] = ldg16(k.w + (long)i * 16);
+      }
+#pragma unroll
+      for (int u = 0; u < WB; ++u) {
+        const int i = ib + u * 256;
+        if (i < nw) *reinterpret_cast<uint4*>(wl + (long)i * 16) = wv[u];
+      }
+    }
+  } else {
+    __syncthreads();        // wsrc
+    for (int ib = tid; ib < nw; ib += 256 * WB) {
+#pragma unroll
+      for (int u = 0; u < WB; ++u) {
+        const int i = ib + u * 256;
+        wv[u] = make_uint4(0u, 0u, 0u, 0u);
+        if (i < nw) {
+          const int src = wsrc[i / TN];
+          if (src >= 0) wv[u] = ldg16(k.w + ((long)(src + n0 + (i % TN))) * 16);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < WB; ++u) {
+        const int i = ib + u * 256;
+        if (i < nw) *reinterpret_cast<uint4*>(wl + (long)i * 16) = wv[u];
+      }
+    }
+  }
+
+  // fragment addressing: fragment f = wave*FW + g0 + i of the tile sits at row f/2, column half f%2
+  const int fb0 = (((wave * FW) / TWF) * k.HW + l16) * PIXB;          // group 0, fragment 0 of this wave
+  const int rowb = k.HW * PIXB;
+  // output addressing (tiles are exact: the host only takes this kernel when OH % TH == 0 and OW % TW == 0)
+  int vo_out[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    if constexpr (WIDE) vo_out[j] = ((wave * FW) / TWF) * k.y_sy + ((q & 1) * 16 + l16) * k.y_sx + (n0 + j * 16 + 8 * (q >> 1)) * ESZ;
+    else vo_out[j] = ((wave * FW) / TWF) * k.y_sy + l16 * k.y_sx + (n0 + j * 16 + 4 * q) * ESZ;
+  }
+  int vo_ad[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) vo_ad[j] = ((wave * FW) / TWF) * k.a_sy + l16 * k.a_sx + (n0 + j * 16 + 4 * q) * ESZ;
+  float s1[NT][4], s2[NT][4];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s1[j][r] = 0.f; s2[j][r] = 0.f; }
+
+  while (tile < ntiles) {
+    // ---- halo of this tile: transform, write to LDS (slots beyond the halo hold zeros and land in the slack of the region) ----
+#pragma unroll
+    for (int u = 0; u < HS; ++u) {
+      uint4 v = __builtin_bit_cast(uint4, hv[u]);
+      if constexpr (XF) {
+        if ((hok >> u) & 1u) {
+          float f[CPU];
+          ET<T>::unpack(v, f);
+#pragma unroll
+          for (int e = 0; e < CPU; ++e) f[e] = fmaxf(fmaf(f[e] - xsub[e], xsc[e], xsh[e]), xlo[e]);
+          v = ET<T>::pack(f);
+        }
+      }
+      *reinterpret_cast<uint4*>(halo_w + u * (PPS * PIXB)) = v;
+    }
+    __syncthreads();
+    const unsigned t = (unsigned)__builtin_amdgcn_readfirstlane(tile);
+    const unsigned rr = udiv_magic(t, k.tx_magic), tx = t - rr * (unsigned)k.tiles_x;
+    const unsigned n = udiv_magic(rr, k.ty_magic), ty = rr - n * (unsigned)k.tiles_y;
+    const int oy0 = (int)ty * TH, ox0 = (int)tx * TW;
+    const int next = tile + gridDim.x;
+    if (next < ntiles) load_halo(next);       // in flight during the MFMAs and stores below
+    __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)(k.y + (long)n * k.y_sn), 0, (int)k.y_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc((void*)(k.ad != nullptr ? k.ad + (long)n * k.a_sn : k.x), 0, k.ad != nullptr ? (int)k.a_bytes : 0, 0x00020000);
+    const int ybase = oy0 * k.y_sy + ox0 * k.y_sx, abase = oy0 * k.a_sy + ox0 * k.a_sx;
+
+#pragma unroll 1
+    for (int g0 = 0; g0 < FW; g0 += FH) {
+      // addend (gradient accumulation of the data-gradient convs): in flight under the MFMA loop
+      ubr_u4 adv4[FH][NT];     // fp32: 16 bytes per fragment
+      ubr_u2 adv2[FH][NT];     // 16-bit types: 8 bytes
+      if (k.ad != nullptr) {
+#pragma unroll
+        for (int i = 0; i < FH; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const int so = abase + ((g0 + i) / TWF) * k.a_sy;
+            if constexpr (WIDE) adv2[i][j] = __builtin_amdgcn_raw_buffer_load_b64(ar, vo_ad[j] + (i % TWF) * 16 * k.a_sx, so, 0);
+            else adv4[i][j] = __builtin_amdgcn_raw_buffer_load_b128(ar, vo_ad[j] + (i % TWF) * 16 * k.a_sx, so, 0);
+          }
+      }
+      f32x4 acc[FH][NT];
+#pragma unroll
+      for (int i = 0; i < FH; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const char* hb = halo + fb0 + (g0 / TWF) * rowb;
+      int off_n = tbl[q];
+      uint4 wf_n[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) wf_n[j] = *reinterpret_cast<const uint4*>(wl + ((q * TN) + j * 16 + l16) * 16);
+      const int nsteps = (k.dbg & 2) ? 1 : k.steps;
+      for (int s = 0; s < nsteps; ++s) {
+        const char* pa = hb + off_n;
+        uint4 wf[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wf[j] = wf_n[j];
+        if (s + 1 < nsteps) {
+          off_n = tbl[4 * (s + 1) + q];
+#pragma unroll
+          for (int j = 0; j < NT; ++j) wf_n[j] = *reinterpret_cast<const uint4*>(wl + (((4 * (s + 1) + q) * TN) + j * 16 + l16) * 16);
+        }
+        uint4 a[FH];
+        a[0] = *reinterpret_cast<const uint4*>(pa);
+        a[1] = *reinterpret_cast<const uint4*>(pa + 16 * PIXB);
+        a[2] = *reinterpret_cast<const uint4*>(pa + rowb);
+        a[3] = *reinterpret_cast<const uint4*>(pa + rowb + 16 * PIXB);
+#pragma unroll
+        for (int i = 0; i < FH; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = mma_step<T>(acc[i][j], wf[j], a[i]);
+      }
+
+      // ---- epilogue of this fragment group ----
+#pragma unroll
+      for (int i = 0; i < FH; i += 2) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          float v[2][4];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[h][r] = acc[i + h][j][r] + bs[j][r];     // (same order of additions as conv_igemm_kernel)
+            if (k.act & 1) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[h][r] = fmaxf(v[h][r], 0.f);
+            }
+            if (k.ad != nullptr) {
+              float a4[4];
+              if constexpr (WIDE) {
+                const uint2 raw = make_uint2(adv2[i + h][j][0], adv2[i + h][j][1]);
+                load4<T>(reinterpret_cast<const char*>(&raw), a4);
+              } else {
+                const uint4 raw = __builtin_bit_cast(uint4, adv4[i + h][j]);
+                ET<T>::unpack(raw, a4);
+              }
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[h][r] += a4[r];
+            }
+            if (k.act & 2) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[h][r] = fmaxf(v[h][r], 0.f);
+            }
+            if (k.stats != nullptr) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) { s1[j][r] += v[h][r]; s2[j][r] += v[h][r] * v[h][r]; }
+            }
+          }
+          const int so = ybase + ((g0 + i) / TWF) * k.y_sy;
+          if constexpr (!LSM) {
+            if (k.dbg & 4) {
+              if (v[0][0] == 1.2345e-30f && v[1][1] == 1.2345e-30f) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[0][0]), yr, vo_out[j], so, 0);
+            } else if constexpr (WIDE) {
+              uint2 X, Y;
+              if constexpr (std::is_same<T, bf16_t>::value) {
+                // Converts and swaps in ONE statement with early-clobber outputs, so that no convert's destination is
+                // a source of its neighbours.  hipcc allocated  v35 <- cvt(v36,v37); v36 <- cvt(v30,v31); v37 <- cvt(...)
+                // back to back, and on gfx950 the second convert's result then came out wrong in lanes 12-15 of every
+                // row (stale / overwritten sources: channels 2-3 and 10-11 of every second pixel row; the f16 build,
+                // whose registers happened not to overlap, was correct).  Wait states by hand (hipcc pads nothing in asm).
+                asm volatile("v_cvt_pk_bf16_f32 %0, %4, %5\n\tv_cvt_pk_bf16_f32 %1, %6, %7\n\tv_cvt_pk_bf16_f32 %2, %8, %9\n\t"
+                             "v_cvt_pk_bf16_f32 %3, %10, %11\n\ts_nop 1\n\tv_permlane16_swap_b32 %0, %2\n\tv_permlane16_swap_b32 %1, %3\n\ts_nop 3"
+                             : "=&v"(X.x), "=&v"(X.y), "=&v"(Y.x), "=&v"(Y.y)
+                             : "v"(v[0][0]), "v"(v[0][1]), "v"(v[0][2]), "v"(v[0][3]), "v"(v[1][0]), "v"(v[1][1]), "v"(v[1][2]), "v"(v[1][3]));
+              } else {
+                f16x4_t a, b;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { a[r] = (_Float16)v[0][r]; b[r] = (_Float16)v[1][r]; }
+                X = __builtin_bit_cast(uint2, a); Y = __builtin_bit_cast(uint2, b);
+                // even quads end up with channels 8(q/2)..+7 of fragment i, odd quads with those of fragment i+1
+                asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 3"
+                             : "+v"(X.x), "+v"(Y.x), "+v"(X.y), "+v"(Y.y));
+              }
+              ubr_u4 o = {X.x, X.y, Y.x, Y.y};
+              __builtin_amdgcn_raw_buffer_store_b128(o, yr, vo_out[j], so, 0);
+            } else {
+#pragma unroll
+              for (int h = 0; h < 2; ++h) {
+                ubr_u4 o = {__float_as_uint(v[h][0]), __float_as_uint(v[h][1]), __float_as_uint(v[h][2]), __float_as_uint(v[h][3])};
+                __builtin_amdgcn_raw_buffer_store_b128(o, yr, vo_out[j] + h * 16 * k.y_sx, so, 0);
+              }
+            }
+          } else if (j == 0) {
+            (void)so;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              // fused LogSoftmax over the first Cout (<=16) channels, fp32 NCHW output
+              const int ch = 4 * q;
+              const int f = wave * FW + g0 + i + h;
+              const int oy = oy0 + f / TWF, ox = ox0 + (f % TWF) * 16 + l16;
+              float m = -3.0e38f;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) if (ch + r < k.Cout) m = fmaxf(m, v[h][r]);
+              m = fmaxf(m, __shfl_xor(m, 16, 64));
+              m = fmaxf(m, __shfl_xor(m, 32, 64));
+              float e = 0.f;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) if (ch + r < k.Cout) e += expf(v[h][r] - m);
+              e += __shfl_xor(e, 16, 64);
+              e += __shfl_xor(e, 32, 64);
+              const float lse = m + logf(e);
+              float* o = reinterpret_cast<float*>(k.y);
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (ch + r < k.Cout) o[(((long)n * k.Cout + ch + r) * k.OH + oy) * k.OW + ox] = v[h][r] - lse;
+            }
+          }
+        }
+      }
+    }   // fragment groups
+    tile = next;
+    if (tile < ntiles) __syncthreads();        // every wave is done with this tile's halo image before it is overwritten
+  }
+
+  if (k.stats != nullptr) {
+    // (fp32 partial sums span all tiles of the workgroup: <= 16 tiles x 128 pixels per lane here, then fp64)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float a = wave_quadrow_sum16(s1[j][r]);
+        const float b = wave_quadrow_sum16(s2[j][r]);
+        if (l16 == 0) {
+          red[(wave * TN + j * 16 + 4 * q + r) * 2 + 0] = a;
+          red[(wave * TN + j * 16 + 4 * q + r) * 2 + 1] = b;
+        }
+      }
+    __syncthreads();
+    if (tid < TN) {
+      const int ch = n0 + tid;
+      if (ch < k.Cout) {
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { a += (double)red[(w * TN + tid) * 2]; b += (double)red[(w * TN + tid) * 2 + 1]; }
+        double* st = k.stats + (size_t)(blockIdx.x % UBR_STAT_SLOTS) * 2 * k.Cout;
+        atomicAdd(&st[ch], a);
+        atomicAdd(&st[k.Cout + ch], b);
+      }
+    }
+  }
+}
+
 static thread_local int g_last_conv_cfg[4] = {0, 0, 0, 0};   // FW, NT, TWF, PIPE of this thread's last launch
 struct TileCfg { int FW, NT, TWF; };
 // id -> config; keep in sync with the dispatch switch
@@ -438,9 +877,96 @@ int launch_one(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
   return UBR_OK;
 }
 
+template <typename T, int FW, int NT, int TWF, int UPB, bool XF, bool LSM = false>
+int launch_thin(const ThinK& k, dim3 grid, size_t lds, hipStream_t st) {
+  auto fn = conv_thin_kernel<T, FW, NT, TWF, UPB, XF, LSM>;
+  if (lds > 64 * 1024) {
+    static thread_local size_t maxset = 0;
+    if (lds > maxset) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) { ubr_set_error("ubr_conv: cannot raise LDS limit to %zu: %s", lds, hipGetErrorString(e)); return UBR_ELAUNCH; }
+      maxset = lds;
+    }
+  }
+  ubr_launch(fn, grid, dim3(256), lds, st, k);
+  UBR_LAUNCH_CHECK("ubr_conv");
+  return UBR_OK;
+}
+
+static unsigned magic_u32(unsigned d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + d - 1) / d); }
+
+// Thin layers (conv_thin_kernel): one cin block of 2 or 4 units, stride 1, exact tiling, halo within the register slots,
+// 16-bit outputs storable as whole channel octets.  Returns 1 when the launch was taken.
+template <typename T, int FW, int NT, int TWF>
+int try_thin(const ConvK& c, dim3 grid, hipStream_t st, int* rc) {
+  constexpr int TH = 4 * FW / TWF, TW = TWF * 16, TN = NT * 16;
+  static const bool thin_on = [] { const char* e = getenv("UBR_CONV_THIN"); return !e || atoi(e) != 0; }();
+  const int esz = 16 / ET<T>::CPU;
+  if (!thin_on || c.nblk != 1 || c.S != 1 || (c.UPB != 2 && c.UPB != 4)) return 0;
+  const int HSn = c.UPB == 4 ? 6 : 5;
+  if (c.HH * (int)c.rw > 256 * HSn) return 0;
+  if (c.OH % TH || c.OW % TW) return 0;
+  if (c.epilogue == 0 && esz == 2 && !c.wide_store) return 0;
+  if (c.epilogue == 0 && (c.Cout % 4 || c.Cout_pad != (int)grid.y * TN)) return 0;
+  if (c.x_sy >= (1L << 24) || c.y_sy >= (1L << 24) || (long)c.H * c.x_sy >= (1L << 31) || (long)c.OH * c.y_sy >= (1L << 31)) return 0;
+  if (c.ad != nullptr && (c.a_sy >= (1L << 24) || (long)c.OH * c.a_sy >= (1L << 31))) return 0;
+  const int ntiles = c.tiles_x * c.tiles_y * c.N;
+  if ((unsigned long long)ntiles * (unsigned)c.tiles_x >= (1ull << 32)) return 0;
+  ThinK k{};
+  k.x = c.x; k.x_sn = c.x_sn; k.x_sy = (int)c.x_sy; k.x_sx = (int)c.x_sx; k.x_bytes = (unsigned)((long)c.H * c.x_sy);
+  k.in_sub = c.in_sub; k.in_scale = c.in_scale; k.in_shift = c.in_shift; k.in_lo = c.in_lo;
+  k.w = c.w;
+  k.y = c.y; k.y_sn = c.y_sn; k.y_sy = (int)c.y_sy; k.y_sx = (int)c.y_sx; k.y_bytes = (unsigned)((long)c.OH * c.y_sy);
+  k.ad = c.ad; k.a_sn = c.a_sn; k.a_sy = (int)c.a_sy; k.a_sx = (int)c.a_sx; k.a_bytes = c.ad ? (unsigned)((long)c.OH * c.a_sy) : 0u;
+  k.bias = c.bias; k.stats = c.stats;
+  k.H = c.H; k.W = c.W; k.HW = c.HW; k.nitems = c.HH * (int)c.rw; k.hw_magic = magic_u32((unsigned)c.HW);
+  k.tiles_x = c.tiles_x; k.tiles_y = c.tiles_y; k.ntiles = ntiles;
+  k.tx_magic = magic_u32((unsigned)c.tiles_x); k.ty_magic = magic_u32((unsigned)c.tiles_y);
+  k.steps = c.steps; k.nunits = c.nunits; k.hy_org = c.iy0 + c.dymin; k.hx_org = c.ix0 + c.dxmin; k.dymin = c.dymin; k.dxmin = c.dxmin;
+  k.Cout = c.Cout; k.Cout_pad = c.Cout_pad; k.CU = c.CU; k.OH = c.OH; k.OW = c.OW;
+  k.act = c.act; k.epilogue = c.epilogue; k.wlinear = c.wlinear; k.dbg = c.dbg;
+  for (int t = 0; t < c.ntaps; ++t) { k.dy[t] = c.dy[t]; k.dx[t] = c.dx[t]; k.wt[t] = c.wt[t]; }
+  // LDS: tap-offset + weight-source tables | weight slab | halo (HS slots of the whole workgroup) | statistics scratch
+  const int pixb = c.UPB * 16 + 16;
+  size_t off = ((size_t)2 * 16 * c.steps + 15) & ~(size_t)15;
+  k.wl_off = (int)off; off += (size_t)4 * c.steps * TN * 16;
+  k.halo_off = (int)off; off += (size_t)HSn * (256 / c.UPB) * pixb;
+  k.red_off = (int)off; off += (size_t)4 * TN * 2 * sizeof(float);
+  const size_t lds = off;
+  if (lds > 150 * 1024) return 0;
+  // persistent grid: the workgroups that fit the chip at once (3 per CU by registers), each walking tiles with a stride of the grid
+  static const int wg_per_cu = [] { const char* e = getenv("UBR_CONV_THIN_WGS"); return e ? atoi(e) : 0; }();
+  int per_cu = (int)((150 * 1024) / lds);
+  if (per_cu > 3) per_cu = 3;
+  if (wg_per_cu > 0) per_cu = wg_per_cu;
+  if (per_cu < 1) per_cu = 1;
+  dim3 g(grid.x, grid.y);
+  const unsigned cap = 256u * (unsigned)per_cu / (grid.y ? grid.y : 1);
+  if (g.x > cap && cap > 0) g.x = cap;
+  g_last_conv_cfg[3] = 2;
+  const bool xf = c.in_scale != nullptr;
+  if (c.epilogue == 1) {
+    // conv11 + LogSoftmax (models/ub_uresnet.py:64,143): 7x7 over 16 channels, the 8x32-pixel tile
+    if constexpr (FW == 4 && NT == 1) {
+      if (c.UPB != 2) return 0;
+      *rc = xf ? launch_thin<T, FW, NT, TWF, 2, true, true>(k, g, lds, st) : launch_thin<T, FW, NT, TWF, 2, false, true>(k, g, lds, st);
+      return 1;
+    } else {
+      return 0;
+    }
+  }
+  if (c.UPB == 2) *rc = xf ? launch_thin<T, FW, NT, TWF, 2, true>(k, g, lds, st) : launch_thin<T, FW, NT, TWF, 2, false>(k, g, lds, st);
+  else *rc = xf ? launch_thin<T, FW, NT, TWF, 4, true>(k, g, lds, st) : launch_thin<T, FW, NT, TWF, 4, false>(k, g, lds, st);
+  return 1;
+}
+
 // the cin-block pipeline exists for the 64-cout tiles, when a block's items fit its register slots
 template <typename T, int FW, int NT, int TWF>
 int launch_cfg(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
+  if constexpr (NT <= 2 && TWF == 2) {
+    int rc = UBR_OK;
+    if (try_thin<T, FW, NT, TWF>(k, grid, st, &rc)) return rc;
+  }
   if constexpr (NT == 4) {
     static const bool enabled = [] { const char* e = getenv("UBR_CONV_PIPE"); return !e || atoi(e) != 0; }();
     if (enabled && k.nblk >= 2 && k.HH * (int)k.rw <= 256 * conv_pipe_hslots(FW, TWF) && 4 * k.steps * NT * 16 <= 256 * conv_pipe_wslots(NT))
@@ -508,6 +1034,21 @@ extern "C" void ubr_conv_last_config(int* fw, int* nt, int* twf, int* pipe) {
   if (pipe) *pipe = g_last_conv_cfg[3];
 }
 
+// host mirror of try_thin's conditions (a layer property plus exact tiling; never the batch size)
+static bool thin_eligible(const ubr_conv_desc* d, int cfg, const Plan& p, bool wide_ok) {
+  static const bool thin_on = [] { const char* e = getenv("UBR_CONV_THIN"); return !e || atoi(e) != 0; }();
+  const TileCfg& c = kCfgs[cfg];
+  if (!thin_on || c.TWF != 2 || c.NT > 2 || (c.FW % 4)) return false;
+  const int cpu = ubr_cpu(d->dtype), esz = ubr_esize(d->dtype);
+  const int CU = d->Cin / cpu, TH = 4 * c.FW / c.TWF, TW = c.TWF * 16;
+  if (p.UPB != CU || d->S != 1 || (p.UPB != 2 && p.UPB != 4)) return false;
+  if ((long)p.HH * p.HW * p.UPB > 256L * (p.UPB == 4 ? 6 : 5)) return false;
+  if (d->OH % TH || d->OW % TW) return false;
+  if (d->epilogue == 1) return cfg == 1 && p.UPB == 2;
+  if (esz == 2 && !wide_ok) return false;
+  return d->Cout % 4 == 0;
+}
+
 extern "C" int ubr_conv(const ubr_conv_desc* d, void* stream) {
   UBR_CHECK(d != nullptr, "ubr_conv: null descriptor");
   UBR_CHECK(ubr_dtype_ok(d->dtype), "ubr_conv: bad dtype %d", d->dtype);
@@ -545,6 +1086,9 @@ extern "C" int ubr_conv(const ubr_conv_desc* d, void* stream) {
   }
   UBR_CHECK(dymax - dymin <= 16 && dxmax - dxmin <= 16, "ubr_conv: tap extent too large");
 
+  // 16-byte stores of channel octets need every octet whole and 16-byte aligned in the output view
+  const bool wide_ok = d->epilogue == 0 && esz == 2 && d->Cout % 8 == 0 && (((uintptr_t)d->y.p) % 16) == 0 && (d->y.sx * esz) % 16 == 0 &&
+                       (d->y.sy * esz) % 16 == 0 && (d->y.sn * esz) % 16 == 0;
   // ---- choose a tile configuration ----
   Plan best{}; bool have = false;
   if (d->tile_hint > 0) {
@@ -555,6 +1099,17 @@ extern "C" int ubr_conv(const ubr_conv_desc* d, void* stream) {
     // widest channel tile that divides Cout_pad; then the largest pixel tile that still yields
     // >= 512 workgroups (2 per CU), else the smallest tile.
     const int order_by_nt[3][4] = {{3, 4, 5, -1}, {2, 6, 8, -1}, {0, 1, 7, 9}};
+    // thin layers (one cin block, <= 32 output channels): the largest tile the persistent conv_thin_kernel can take wins outright
+    if (d->Cout_pad <= 32) {
+      const int g = d->Cout_pad == 32 ? 1 : 2;
+      for (int i = 0; i < 4 && !have; ++i) {
+        const int cfg = order_by_nt[g][i];
+        if (cfg < 0 || kCfgs[cfg].TWF != 2) continue;
+        Plan p{};
+        if (!plan_for(d, cfg, dymin, dymax, dxmin, dxmax, &p)) continue;
+        if (thin_eligible(d, cfg, p, wide_ok)) { best = p; have = true; }
+      }
+    }
     for (int g = 0; g < 3 && !have; ++g) {
       Plan cand{}; bool any = false;
       for (int i = 0; i < 4; ++i) {
@@ -596,7 +1151,14 @@ extern "C" int ubr_conv(const ubr_conv_desc* d, void* stream) {
   k.step_goff = k.step_hy * k.x_sy32 + (k.step_j >> k.lgUPB) * k.x_sx32;
   k.wrap_goff = k.x_sy32 - best.HW * k.x_sx32;
   k.wl_off = best.wl_off; k.halo_off = best.halo_off; k.red_off = best.red_off;
-  k.epilogue = d->epilogue; k.act = d->act;
+  k.epilogue = d->epilogue; k.act = d->act; k.N = d->N;
+  {
+    bool nat = d->Cout_pad == kCfgs[best.cfg].NT * 16;
+    for (int t = 0; t < d->ntaps && nat; ++t) nat = d->wt[t] == t;
+    k.wlinear = nat ? 1 : 0;
+  }
+  { static const int dbg = [] { const char* e = getenv("UBR_CONV_DBG"); return e ? atoi(e) : 0; }(); k.dbg = dbg; }
+  k.wide_store = wide_ok ? 1 : 0;
   for (int t = 0; t < d->ntaps; ++t) { k.dy[t] = d->dy[t]; k.dx[t] = d->dx[t]; k.wt[t] = d->wt[t]; }
 
   const TileCfg& c = kCfgs[best.cfg];
