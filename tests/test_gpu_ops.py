@@ -88,6 +88,16 @@ CONV_CASES = [
     (1, 96, 128, 16, 16, 3, 1, 1, False, False, True, True, 0),
     (1, 48, 64, 32, 32, 3, 1, 1, True, False, True, False, 0),
     (2, 64, 96, 16, 16, 7, 1, 1, False, True, False, False, 0),
+    # conv_wide_kernel tiles (hint 101..106): 128- and 64-cout workgroup tiles, waves laid out WP x WN
+    (1, 16, 32, 64, 128, 3, 1, 1, True, False, True, False, 101),
+    (1, 8, 32, 128, 128, 3, 1, 1, False, True, True, True, 102),
+    (1, 32, 32, 64, 64, 3, 1, 1, True, False, True, False, 103),
+    (2, 16, 16, 128, 128, 3, 1, 1, False, False, True, True, 104),
+    (1, 8, 16, 64, 128, 3, 1, 1, True, True, False, False, 105),
+    (1, 16, 16, 32, 64, 3, 1, 1, False, True, True, False, 106),
+    (1, 12, 40, 64, 128, 3, 1, 1, True, False, True, False, 102),    # ragged edges
+    (2, 20, 24, 96, 192, 3, 1, 1, False, False, True, False, 0),      # auto choice, Cout multiple of 64 only
+    (1, 16, 32, 64, 128, 1, 1, 1, False, False, True, False, 101),    # 1x1
 ]
 
 

@@ -423,30 +423,44 @@ __global__ __launch_bounds__(256, ((NT == 4 && FW <= 2 && !PIPE) ? 4 : 2)) void 
 //   * <= 128 VGPRs: four workgroups per CU alone, and two beside the 240-VGPR weight-gradient kernels of the side stream
 //     (the 165-VGPR kernel dropped to ONE workgroup per CU there).
 // ---------------------------------------------------------------------------------------------
-template <typename T> __device__ __forceinline__ void store_frag_pair(char* p0, char* p1, bool ok0, bool ok1, const float* v0, const float* v1, int q);
-template <> __device__ __forceinline__ void store_frag_pair<float>(char* p0, char* p1, bool ok0, bool ok1, const float* v0, const float* v1, int q) {
-  if (ok0) store4<float>(p0, v0);
-  if (ok1) store4<float>(p1, v1);
+// Two pixel fragments' 4-channel groups (fp32) -> this lane's 16 output bytes after the quad exchange (see store_pair16).
+// bf16: converts and swaps in ONE asm statement with early-clobber outputs, so that no convert's destination is a source of
+// its neighbours.  hipcc allocated  v35 <- cvt(v36,v37); v36 <- cvt(v30,v31); v37 <- cvt(...)  back to back, and on gfx950
+// the second convert's result then came out wrong in lanes 12-15 of every row (channels 2-3 / 10-11 of every second pixel
+// row; the f16 build, whose registers happened not to overlap, was correct).  Wait states by hand: hipcc pads nothing in asm.
+template <typename T> __device__ __forceinline__ uint4 pack_swap_pair(const float* v0, const float* v1);
+template <> __device__ __forceinline__ uint4 pack_swap_pair<bf16_t>(const float* v0, const float* v1) {
+  uint2 X, Y;
+  asm volatile("v_cvt_pk_bf16_f32 %0, %4, %5\n\tv_cvt_pk_bf16_f32 %1, %6, %7\n\tv_cvt_pk_bf16_f32 %2, %8, %9\n\t"
+               "v_cvt_pk_bf16_f32 %3, %10, %11\n\ts_nop 1\n\tv_permlane16_swap_b32 %0, %2\n\tv_permlane16_swap_b32 %1, %3\n\ts_nop 3"
+               : "=&v"(X.x), "=&v"(X.y), "=&v"(Y.x), "=&v"(Y.y)
+               : "v"(v0[0]), "v"(v0[1]), "v"(v0[2]), "v"(v0[3]), "v"(v1[0]), "v"(v1[1]), "v"(v1[2]), "v"(v1[3]));
+  return make_uint4(X.x, X.y, Y.x, Y.y);
 }
-// 16-bit types: lane (q, l16) holds channels 4q..4q+3 of pixel l16 of fragment 0 (X) and of fragment 1 (Y), 8 bytes each.
-// v_permlane16_swap exchanges the odd quads of X with the even quads of Y: afterwards an even quad holds channels
-// 4q..4q+7 of its fragment-0 pixel and an odd quad channels 4(q-1)..4q+3 of its fragment-1 pixel -- 16 contiguous bytes.
-__device__ __forceinline__ void store_pair16(char* p0, char* p1, bool ok0, bool ok1, uint2 X, uint2 Y, int q) {
-  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 3" : "+v"(X.x), "+v"(Y.x), "+v"(X.y), "+v"(Y.y));
-  const uint4 v = make_uint4(X.x, X.y, Y.x, Y.y);
-  const bool odd = (q & 1) != 0;
-  char* p = odd ? (p1 - 8) : p0;          // p1 addresses channel 4q of fragment 1: an odd quad's 16 bytes start one quad lower
-  if (odd ? ok1 : ok0) *reinterpret_cast<uint4*>(p) = v;
-}
-template <> __device__ __forceinline__ void store_frag_pair<bf16_t>(char* p0, char* p1, bool ok0, bool ok1, const float* v0, const float* v1, int q) {
-  store_pair16(p0, p1, ok0, ok1, make_uint2(ET<bf16_t>::pk2(v0[0], v0[1]), ET<bf16_t>::pk2(v0[2], v0[3])),
-               make_uint2(ET<bf16_t>::pk2(v1[0], v1[1]), ET<bf16_t>::pk2(v1[2], v1[3])), q);
-}
-template <> __device__ __forceinline__ void store_frag_pair<f16_t>(char* p0, char* p1, bool ok0, bool ok1, const float* v0, const float* v1, int q) {
+template <> __device__ __forceinline__ uint4 pack_swap_pair<f16_t>(const float* v0, const float* v1) {
   f16x4_t a, b;
 #pragma unroll
   for (int r = 0; r < 4; ++r) { a[r] = (_Float16)v0[r]; b[r] = (_Float16)v1[r]; }
-  store_pair16(p0, p1, ok0, ok1, __builtin_bit_cast(uint2, a), __builtin_bit_cast(uint2, b), q);
+  uint2 X = __builtin_bit_cast(uint2, a), Y = __builtin_bit_cast(uint2, b);
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 3" : "+v"(X.x), "+v"(Y.x), "+v"(X.y), "+v"(Y.y));
+  return make_uint4(X.x, X.y, Y.x, Y.y);
+}
+template <> __device__ __forceinline__ uint4 pack_swap_pair<float>(const float* v0, const float* v1) { return make_uint4(0u, 0u, 0u, 0u); }
+
+// 16-bit types: lane (q, l16) holds channels 4q..4q+3 of pixel l16 of fragment 0 (X) and of fragment 1 (Y), 8 bytes each.
+// v_permlane16_swap exchanges the odd quads of X with the even quads of Y: afterwards an even quad holds channels
+// 4q..4q+7 of its fragment-0 pixel and an odd quad channels 4(q-1)..4q+3 of its fragment-1 pixel -- 16 contiguous bytes.
+// p0 / p1 address channel 4q of the lane's pixel in fragment 0 / 1.
+template <typename T> __device__ __forceinline__ void store_frag_pair(char* p0, char* p1, bool ok0, bool ok1, const float* v0, const float* v1, int q) {
+  if constexpr (std::is_same<T, float>::value) {
+    if (ok0) store4<float>(p0, v0);
+    if (ok1) store4<float>(p1, v1);
+  } else {
+    const uint4 v = pack_swap_pair<T>(v0, v1);
+    const bool odd = (q & 1) != 0;
+    char* p = odd ? (p1 - 8) : p0;          // an odd quad's 16 bytes start one quad (4 channels) lower
+    if (odd ? ok1 : ok0) *reinterpret_cast<uint4*>(p) = v;
+  }
 }
 
 typedef __attribute__((ext_vector_type(4))) unsigned ubr_u4;
@@ -755,27 +769,8 @@ __global__ __launch_bounds__(256, 3) void conv_thin_kernel(const ThinK k) {
             if (k.dbg & 4) {
               if (v[0][0] == 1.2345e-30f && v[1][1] == 1.2345e-30f) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[0][0]), yr, vo_out[j], so, 0);
             } else if constexpr (WIDE) {
-              uint2 X, Y;
-              if constexpr (std::is_same<T, bf16_t>::value) {
-                // Converts and swaps in ONE statement with early-clobber outputs, so that no convert's destination is
-                // a source of its neighbours.  hipcc allocated  v35 <- cvt(v36,v37); v36 <- cvt(v30,v31); v37 <- cvt(...)
-                // back to back, and on gfx950 the second convert's result then came out wrong in lanes 12-15 of every
-                // row (stale / overwritten sources: channels 2-3 and 10-11 of every second pixel row; the f16 build,
-                // whose registers happened not to overlap, was correct).  Wait states by hand (hipcc pads nothing in asm).
-                asm volatile("v_cvt_pk_bf16_f32 %0, %4, %5\n\tv_cvt_pk_bf16_f32 %1, %6, %7\n\tv_cvt_pk_bf16_f32 %2, %8, %9\n\t"
-                             "v_cvt_pk_bf16_f32 %3, %10, %11\n\ts_nop 1\n\tv_permlane16_swap_b32 %0, %2\n\tv_permlane16_swap_b32 %1, %3\n\ts_nop 3"
-                             : "=&v"(X.x), "=&v"(X.y), "=&v"(Y.x), "=&v"(Y.y)
-                             : "v"(v[0][0]), "v"(v[0][1]), "v"(v[0][2]), "v"(v[0][3]), "v"(v[1][0]), "v"(v[1][1]), "v"(v[1][2]), "v"(v[1][3]));
-              } else {
-                f16x4_t a, b;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { a[r] = (_Float16)v[0][r]; b[r] = (_Float16)v[1][r]; }
-                X = __builtin_bit_cast(uint2, a); Y = __builtin_bit_cast(uint2, b);
-                // even quads end up with channels 8(q/2)..+7 of fragment i, odd quads with those of fragment i+1
-                asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 3"
-                             : "+v"(X.x), "+v"(Y.x), "+v"(X.y), "+v"(Y.y));
-              }
-              ubr_u4 o = {X.x, X.y, Y.x, Y.y};
+              const uint4 pk = pack_swap_pair<T>(v[0], v[1]);
+              ubr_u4 o = {pk.x, pk.y, pk.z, pk.w};
               __builtin_amdgcn_raw_buffer_store_b128(o, yr, vo_out[j], so, 0);
             } else {
 #pragma unroll
@@ -836,6 +831,250 @@ __global__ __launch_bounds__(256, 3) void conv_thin_kernel(const ThinK k) {
         double a = 0.0, b = 0.0;
 #pragma unroll
         for (int w = 0; w < 4; ++w) { a += (double)red[(w * TN + tid) * 2]; b += (double)red[(w * TN + tid) * 2 + 1]; }
+        double* st = k.stats + (size_t)(blockIdx.x % UBR_STAT_SLOTS) * 2 * k.Cout;
+        atomicAdd(&st[ch], a);
+        atomicAdd(&st[k.Cout + ch], b);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Wide layers (Cout >= 64, several cin blocks, stride 1): the MFMA-bound half of the network (64^2 ... 16^2 maps).
+// conv_igemm_kernel runs them with a 64-cout tile, 4 waves side by side along the pixels and two workgroups per CU: every
+// MFMA then needs half a fresh 1 KB LDS fragment (8 reads per 16 MFMAs per wave, 8 waves per CU = the LDS read port is
+// saturated whenever both workgroups compute), a barrier pair comes every 72 MFMAs, and each 64-cout tile re-reads the
+// activations.  Here ONE workgroup per CU owns a 128-cout (WN = 2) or 64-cout tile and up to 512 pixels:
+//   * waves are laid out WP x WN; a wave's register tile is FW pixel fragments x NT cout fragments (8 x 4 = 128 accumulator
+//     registers): 12 LDS fragment reads feed 32 MFMAs, 4 waves per CU -> 37 % of the LDS read rate instead of 100 %;
+//   * cin blocks of 4 units: 288 MFMAs per wave between barrier pairs; the next block's halo and weight slab are loaded
+//     into registers (the whole 512-entry file is available at one wave per SIMD) under the current block's MFMAs;
+//   * the activations are read once per 128 output channels.
+// Arithmetic per output element is exactly conv_igemm_kernel's (same order over cin blocks, taps and units), so results do
+// not depend on which kernel or tile a launch gets.
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int wide_hslots(int fw, int twf, int wn) { return (((4 / wn) * fw / twf + 2) * (twf * 16 + 2) * 4 + 255) / 256; }
+__host__ __device__ constexpr int wide_wslots(int nt, int wn) { return (36 * nt * 16 * wn + 255) / 256; }
+
+template <typename T, int FW, int NT, int TWF, int WN>
+__global__ __launch_bounds__(256, 1) void conv_wide_kernel(const ConvK k) {
+  constexpr int WP = 4 / WN;
+  constexpr int TN = NT * 16 * WN;
+  constexpr int F = WP * FW;
+  constexpr int TH = F / TWF;
+  constexpr int TW = TWF * 16;
+  constexpr int CPU = ET<T>::CPU;
+  constexpr int ESZ = 16 / CPU;
+  constexpr int HS = wide_hslots(FW, TWF, WN), WS = wide_wslots(NT, WN);
+  static_assert(F % TWF == 0 && FW % 2 == 0, "tile shape");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* tbl = reinterpret_cast<int*>(smem);
+  char* wl = smem + k.wl_off;
+  char* halo = smem + k.halo_off;
+  float* red = reinterpret_cast<float*>(smem + k.red_off);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, l16 = lane & 15;
+  const int wn = wave % WN, wp = wave / WN;
+  int t = blockIdx.x;
+  const int tx = t % k.tiles_x; t /= k.tiles_x;
+  const int ty = t % k.tiles_y;
+  const int n = t / k.tiles_y;
+  const int n0 = blockIdx.y * TN;
+  const int oy0 = ty * TH, ox0 = tx * TW;
+  const int hy0 = oy0 * k.S + k.iy0 + k.dymin, hx0 = ox0 * k.S + k.ix0 + k.dxmin;
+
+  int* wsrc = tbl + 4 * k.steps;
+  for (int u = tid; u < 4 * k.steps; u += 256) {
+    int off = 0, v = -1;
+    if (u < k.nunits) {
+      const int tap = u >> k.lgUPB, cc = u & (k.UPB - 1);
+      off = ((k.dy[tap] - k.dymin) * k.HW + (k.dx[tap] - k.dxmin)) * k.pixb + cc * 16;
+      v = ((int)k.wt[tap] * k.CU + cc) * k.Cout_pad;
+    }
+    tbl[u] = off;
+    wsrc[u] = v;
+  }
+  __syncthreads();
+
+  f32x4 acc[FW][NT];
+#pragma unroll
+  for (int i = 0; i < FW; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int fragbase[FW];
+#pragma unroll
+  for (int i = 0; i < FW; ++i) {
+    const int f = wp * FW + i;
+    fragbase[i] = (((f / TWF) * k.S) * k.HW + (f % TWF) * 16 * k.S) * k.pixb + l16 * k.S * k.pixb;
+  }
+
+  const char* xn = k.x + (long)n * k.x_sn;
+  const int nitems = k.HH * (int)k.rw;
+  const bool has_xf = k.in_scale != nullptr;
+  uint4 hv[HS], wv[WS];
+  unsigned hok = 0u;
+  const int c = tid & (k.UPB - 1);
+  const int hy00 = (int)__umulhi((unsigned)tid, k.rw_magic);
+  const int j00 = tid - hy00 * (int)k.rw;
+  const int nw = 4 * k.steps * TN;
+  auto load_blk = [&](int blk) {
+    const int ch0 = (blk * k.UPB + c) * CPU;
+    const char* xc = xn + (long)ch0 * ESZ;
+    int hy = hy00, j = j00;
+    int goff = (hy0 + hy) * k.x_sy32 + (hx0 + (j >> k.lgUPB)) * k.x_sx32;
+    hok = 0u;
+#pragma unroll
+    for (int u = 0; u < HS; ++u) {
+      const int iy = hy0 + hy, ix = hx0 + (j >> k.lgUPB);
+      const bool ok = (tid + u * 256 < nitems) && (unsigned)iy < (unsigned)k.H && (unsigned)ix < (unsigned)k.W;
+      hv[u] = make_uint4(0u, 0u, 0u, 0u);
+      if (ok) { hv[u] = ldg16(xc + goff); hok |= 1u << u; }
+      j += k.step_j; hy += k.step_hy; goff += k.step_goff;
+      if (j >= (int)k.rw) { j -= (int)k.rw; hy += 1; goff += k.wrap_goff; }
+    }
+    const int boff = blk * k.UPB * k.Cout_pad + n0;
+#pragma unroll
+    for (int u = 0; u < WS; ++u) {
+      const int i = tid + u * 256;
+      wv[u] = make_uint4(0u, 0u, 0u, 0u);
+      if (i < nw) {
+        const int src = wsrc[i / TN];
+        if (src >= 0) wv[u] = ldg16(k.w + ((long)(src + boff + (i % TN))) * 16);
+      }
+    }
+  };
+  auto store_blk = [&](int blk) {
+    const int ch0 = (blk * k.UPB + c) * CPU;
+    float xsub[CPU], xsc[CPU], xsh[CPU], xlo[CPU];
+    if (has_xf) {
+#pragma unroll
+      for (int e = 0; e < CPU; ++e) { xsub[e] = k.in_sub[ch0 + e]; xsc[e] = k.in_scale[ch0 + e]; xsh[e] = k.in_shift[ch0 + e]; xlo[e] = k.in_lo[ch0 + e]; }
+    }
+#pragma unroll
+    for (int u = 0; u < HS; ++u) {
+      const int i = tid + u * 256;
+      uint4 v = hv[u];
+      if (has_xf && ((hok >> u) & 1u)) {
+        float f[CPU];
+        ET<T>::unpack(v, f);
+#pragma unroll
+        for (int e = 0; e < CPU; ++e) f[e] = fmaxf(fmaf(f[e] - xsub[e], xsc[e], xsh[e]), xlo[e]);
+        v = ET<T>::pack(f);
+      }
+      if (i < nitems) *reinterpret_cast<uint4*>(halo + (i >> k.lgUPB) * k.pixb + c * 16) = v;
+    }
+#pragma unroll
+    for (int u = 0; u < WS; ++u) {
+      const int i = tid + u * 256;
+      if (i < nw) *reinterpret_cast<uint4*>(wl + (long)i * 16) = wv[u];
+    }
+  };
+  const char* wlw = wl + ((q * TN) + wn * NT * 16 + l16) * 16;       // this lane's weight fragment column, step 0
+  load_blk(0);
+  for (int blk = 0; blk < k.nblk; ++blk) {
+    if (blk) __syncthreads();          // previous block's fragments fully read
+    store_blk(blk);
+    __syncthreads();
+    if (blk + 1 < k.nblk) load_blk(blk + 1);
+    for (int s = 0; s < k.steps; ++s) {
+      const int off = tbl[4 * s + q];
+      uint4 wf[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const uint4*>(wlw + (s * 4 * TN + j * 16) * 16);
+#pragma unroll
+      for (int i = 0; i < FW; ++i) {
+        const uint4 a = *reinterpret_cast<const uint4*>(halo + fragbase[i] + off);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = mma_step<T>(acc[i][j], wf[j], a);
+      }
+    }
+  }
+
+  // ---------------------------------- epilogue ----------------------------------
+  float bs[NT][4];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ch = n0 + (wn * NT + j) * 16 + 4 * q + r;
+      bs[j][r] = (k.bias != nullptr && ch < k.Cout) ? k.bias[ch] : 0.f;
+    }
+  float s1[NT][4], s2[NT][4];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s1[j][r] = 0.f; s2[j][r] = 0.f; }
+
+#pragma unroll
+  for (int i = 0; i < FW; i += 2) {
+    int oy[2], ox[2];
+    bool valid[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int f = wp * FW + i + h;
+      oy[h] = oy0 + f / TWF; ox[h] = ox0 + (f % TWF) * 16 + l16;
+      valid[h] = (oy[h] < k.OH) && (ox[h] < k.OW);
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int ch = n0 + (wn * NT + j) * 16 + 4 * q;
+      float v[2][4];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[h][r] = acc[i + h][j][r] + bs[j][r];
+        if (k.act & 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[h][r] = fmaxf(v[h][r], 0.f);
+        }
+        if (k.ad != nullptr && valid[h] && ch < k.Cout) {
+          float a4[4];
+          load4<T>(k.ad + (long)n * k.a_sn + (long)oy[h] * k.a_sy + (long)ox[h] * k.a_sx + (long)ch * ESZ, a4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[h][r] += a4[r];
+        }
+        if (k.act & 2) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[h][r] = fmaxf(v[h][r], 0.f);
+        }
+        if (k.stats != nullptr && valid[h]) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { s1[j][r] += v[h][r]; s2[j][r] += v[h][r] * v[h][r]; }
+        }
+      }
+      char* p0 = k.y + (long)n * k.y_sn + (long)oy[0] * k.y_sy + (long)ox[0] * k.y_sx + (long)ch * ESZ;
+      char* p1 = k.y + (long)n * k.y_sn + (long)oy[1] * k.y_sy + (long)ox[1] * k.y_sx + (long)ch * ESZ;
+      if (k.wide_store) {
+        // (Cout % 8 == 0: a lane's partner quad is in range whenever the lane is; the exchange needs every lane, so it runs
+        // unconditionally and only the store is predicated)
+        store_frag_pair<T>(p0, p1, valid[0] && ch < k.Cout, valid[1] && ch < k.Cout, v[0], v[1], q);
+      } else {
+        if (valid[0] && ch < k.Cout) store4<T>(p0, v[0]);
+        if (valid[1] && ch < k.Cout) store4<T>(p1, v[1]);
+      }
+    }
+  }
+
+  if (k.stats != nullptr) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float a = wave_quadrow_sum16(s1[j][r]);
+        const float b = wave_quadrow_sum16(s2[j][r]);
+        if (l16 == 0) {
+          red[(wp * TN + (wn * NT + j) * 16 + 4 * q + r) * 2 + 0] = a;
+          red[(wp * TN + (wn * NT + j) * 16 + 4 * q + r) * 2 + 1] = b;
+        }
+      }
+    __syncthreads();
+    if (tid < TN) {
+      const int ch = n0 + tid;
+      if (ch < k.Cout) {
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int w = 0; w < WP; ++w) { a += (double)red[(w * TN + tid) * 2]; b += (double)red[(w * TN + tid) * 2 + 1]; }
         double* st = k.stats + (size_t)(blockIdx.x % UBR_STAT_SLOTS) * 2 * k.Cout;
         atomicAdd(&st[ch], a);
         atomicAdd(&st[k.Cout + ch], b);
@@ -976,8 +1215,40 @@ int launch_cfg(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
   return launch_one<T, FW, NT, TWF, false>(k, grid, lds, st);
 }
 
+template <typename T, int FW, int NT, int TWF, int WN>
+int launch_wide_one(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
+  auto fn = conv_wide_kernel<T, FW, NT, TWF, WN>;
+  if (lds > 64 * 1024) {
+    static thread_local size_t maxset = 0;
+    if (lds > maxset) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) { ubr_set_error("ubr_conv: cannot raise LDS limit to %zu: %s", lds, hipGetErrorString(e)); return UBR_ELAUNCH; }
+      maxset = lds;
+    }
+  }
+  ubr_launch(fn, grid, dim3(256), lds, st, k);
+  UBR_LAUNCH_CHECK("ubr_conv");
+  return UBR_OK;
+}
+
+template <typename T>
+int launch_wide(int wi, const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
+  g_last_conv_cfg[3] = 3;
+  switch (wi) {
+    case 0: return launch_wide_one<T, 8, 4, 2, 2>(k, grid, lds, st);
+    case 1: return launch_wide_one<T, 4, 4, 2, 2>(k, grid, lds, st);
+    case 2: return launch_wide_one<T, 8, 4, 2, 1>(k, grid, lds, st);
+    case 3: return launch_wide_one<T, 4, 4, 1, 2>(k, grid, lds, st);
+    case 4: return launch_wide_one<T, 2, 4, 1, 2>(k, grid, lds, st);
+    case 5: return launch_wide_one<T, 4, 4, 1, 1>(k, grid, lds, st);
+  }
+  ubr_set_error("ubr_conv: bad wide tile %d", wi);
+  return UBR_EINVAL;
+}
+
 template <typename T>
 int launch_T(int cfg, const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
+  if (cfg >= 100) return launch_wide<T>(cfg - 100, k, grid, lds, st);
   switch (cfg) {
     case 0: return launch_cfg<T, 8, 1, 2>(k, grid, lds, st);
     case 1: return launch_cfg<T, 4, 1, 2>(k, grid, lds, st);
@@ -996,11 +1267,9 @@ int launch_T(int cfg, const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
 
 struct Plan { int cfg; size_t lds; int UPB, steps, HH, HW, pixb, wl_off, halo_off, red_off, tiles_x, tiles_y; };
 
-static bool plan_for(const ubr_conv_desc* d, int cfg, int dymin, int dymax, int dxmin, int dxmax, Plan* p) {
-  const TileCfg& c = kCfgs[cfg];
-  const int TN = c.NT * 16, TH = 4 * c.FW / c.TWF, TW = c.TWF * 16;
+static bool plan_tile(const ubr_conv_desc* d, int cfg, int TH, int TW, int TN, int dymin, int dymax, int dxmin, int dxmax, Plan* p) {
   if (d->Cout_pad % TN) return false;
-  if (d->epilogue == 1 && c.NT != 1) return false;
+  if (d->epilogue == 1 && TN != 16) return false;
   const int cpu = ubr_cpu(d->dtype);
   const int CU = d->Cin / cpu;
   int UPB = (CU % 4 == 0) ? 4 : (CU % 2 == 0 ? 2 : 1);
@@ -1023,6 +1292,35 @@ static bool plan_for(const ubr_conv_desc* d, int cfg, int dymin, int dymax, int 
   p->tiles_x = ubr_cdiv(d->OW, TW); p->tiles_y = ubr_cdiv(d->OH, TH);
   if ((size_t)HH * HW * UPB >= 60000) return false;   // exact-division bound of the magic multiply
   return off <= 160 * 1024;
+}
+
+static bool plan_for(const ubr_conv_desc* d, int cfg, int dymin, int dymax, int dxmin, int dxmax, Plan* p) {
+  const TileCfg& c = kCfgs[cfg];
+  return plan_tile(d, cfg, 4 * c.FW / c.TWF, c.TWF * 16, c.NT * 16, dymin, dymax, dxmin, dxmax, p);
+}
+
+// conv_wide_kernel tiles: {FW, NT, TWF, WN}; id = 100 + index
+struct WideCfg { int FW, NT, TWF, WN; };
+static const WideCfg kWide[] = {
+    {8, 4, 2, 2},   // 100:  8x32 px x 128 ch
+    {4, 4, 2, 2},   // 101:  4x32 px x 128 ch
+    {8, 4, 2, 1},   // 102: 16x32 px x  64 ch
+    {4, 4, 1, 2},   // 103:  8x16 px x 128 ch
+    {2, 4, 1, 2},   // 104:  4x16 px x 128 ch
+    {4, 4, 1, 1},   // 105: 16x16 px x  64 ch
+};
+constexpr int kNumWide = sizeof(kWide) / sizeof(kWide[0]);
+
+static bool plan_wide(const ubr_conv_desc* d, int wi, int dymin, int dymax, int dxmin, int dxmax, Plan* p) {
+  const WideCfg& c = kWide[wi];
+  const int WP = 4 / c.WN, TH = WP * c.FW / c.TWF, TW = c.TWF * 16, TN = c.NT * 16 * c.WN;
+  if (d->S != 1 || d->epilogue != 0 || d->ntaps > 9) return false;
+  if (!plan_tile(d, 100 + wi, TH, TW, TN, dymin, dymax, dxmin, dxmax, p)) return false;
+  if (p->UPB != 4) return false;
+  if ((long)p->HH * p->HW * 4 > 256L * wide_hslots(c.FW, c.TWF, c.WN)) return false;     // register slots of the block pipeline
+  if (4L * p->steps * TN > 256L * wide_wslots(c.NT, c.WN)) return false;
+  if (c.TWF == 2 && d->OW < 32) return false;
+  return true;
 }
 
 }  // namespace
@@ -1091,7 +1389,11 @@ extern "C" int ubr_conv(const ubr_conv_desc* d, void* stream) {
                        (d->y.sy * esz) % 16 == 0 && (d->y.sn * esz) % 16 == 0;
   // ---- choose a tile configuration ----
   Plan best{}; bool have = false;
-  if (d->tile_hint > 0) {
+  if (d->tile_hint > 100) {        // 101.. = conv_wide_kernel tiles (tests)
+    UBR_CHECK(d->tile_hint <= 100 + kNumWide, "ubr_conv: tile_hint %d out of range", d->tile_hint);
+    have = plan_wide(d, d->tile_hint - 101, dymin, dymax, dxmin, dxmax, &best);
+    UBR_CHECK(have, "ubr_conv: wide tile_hint %d does not fit this shape", d->tile_hint);
+  } else if (d->tile_hint > 0) {
     UBR_CHECK(d->tile_hint <= kNumCfgs, "ubr_conv: tile_hint %d out of range", d->tile_hint);
     have = plan_for(d, d->tile_hint - 1, dymin, dymax, dxmin, dxmax, &best);
     UBR_CHECK(have, "ubr_conv: tile_hint %d does not fit this shape", d->tile_hint);
@@ -1099,6 +1401,28 @@ extern "C" int ubr_conv(const ubr_conv_desc* d, void* stream) {
     // widest channel tile that divides Cout_pad; then the largest pixel tile that still yields
     // >= 512 workgroups (2 per CU), else the smallest tile.
     const int order_by_nt[3][4] = {{3, 4, 5, -1}, {2, 6, 8, -1}, {0, 1, 7, 9}};
+    // wide layers (Cout a multiple of 64, stride 1, <= 9 taps, 4-unit cin blocks): the largest conv_wide_kernel tile that still
+    // yields one workgroup per CU; 128-cout tiles before 64-cout ones
+    {
+      static const bool wide_on = [] { const char* e = getenv("UBR_CONV_WIDE"); return e && atoi(e) != 0; }();   // off by default: see DESIGN.md section 8 (measured)
+      static const int wide_min = [] { const char* e = getenv("UBR_CONV_WIDE_MINWG"); return e ? atoi(e) : 256; }();
+      if (wide_on && d->Cout_pad % 64 == 0) {
+        Plan cand{}; bool any = false;
+        const int order128[] = {0, 1, 3, 4}, order64[] = {2, 5};
+        const bool c128 = d->Cout_pad % 128 == 0;
+        const int* ord = c128 ? order128 : order64;
+        const int nord = c128 ? 4 : 2;
+        for (int i = 0; i < nord && !have; ++i) {
+          Plan p{};
+          if (!plan_wide(d, ord[i], dymin, dymax, dxmin, dxmax, &p)) continue;
+          const WideCfg& c = kWide[ord[i]];
+          const long wgs = (long)p.tiles_x * p.tiles_y * d->N * (d->Cout_pad / (c.NT * 16 * c.WN));
+          cand = p; any = true;
+          if (wgs >= wide_min) { best = p; have = true; }
+        }
+        if (!have && any) { best = cand; have = true; }
+      }
+    }
     // thin layers (one cin block, <= 32 output channels): the largest tile the persistent conv_thin_kernel can take wins outright
     if (d->Cout_pad <= 32) {
       const int g = d->Cout_pad == 32 ? 1 : 2;
@@ -1153,7 +1477,7 @@ extern "C" int ubr_conv(const ubr_conv_desc* d, void* stream) {
   k.wl_off = best.wl_off; k.halo_off = best.halo_off; k.red_off = best.red_off;
   k.epilogue = d->epilogue; k.act = d->act; k.N = d->N;
   {
-    bool nat = d->Cout_pad == kCfgs[best.cfg].NT * 16;
+    bool nat = best.cfg < 100 && d->Cout_pad == kCfgs[best.cfg].NT * 16;
     for (int t = 0; t < d->ntaps && nat; ++t) nat = d->wt[t] == t;
     k.wlinear = nat ? 1 : 0;
   }
@@ -1161,9 +1485,12 @@ extern "C" int ubr_conv(const ubr_conv_desc* d, void* stream) {
   k.wide_store = wide_ok ? 1 : 0;
   for (int t = 0; t < d->ntaps; ++t) { k.dy[t] = d->dy[t]; k.dx[t] = d->dx[t]; k.wt[t] = d->wt[t]; }
 
-  const TileCfg& c = kCfgs[best.cfg];
+  TileCfg c{};
+  int tn;
+  if (best.cfg >= 100) { const WideCfg& w = kWide[best.cfg - 100]; c = TileCfg{w.FW, w.NT * w.WN, w.TWF}; tn = w.NT * 16 * w.WN; }
+  else { c = kCfgs[best.cfg]; tn = c.NT * 16; }
   g_last_conv_cfg[0] = c.FW; g_last_conv_cfg[1] = c.NT; g_last_conv_cfg[2] = c.TWF;
-  dim3 grid((unsigned)(best.tiles_x * best.tiles_y * d->N), (unsigned)(d->Cout_pad / (c.NT * 16)));
+  dim3 grid((unsigned)(best.tiles_x * best.tiles_y * d->N), (unsigned)(d->Cout_pad / tn));
   hipStream_t st = (hipStream_t)stream;
   {
     static const bool dbg = [] { const char* e = getenv("UBR_CONV_DEBUG"); return e && atoi(e) != 0; }();
