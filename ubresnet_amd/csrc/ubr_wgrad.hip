@@ -197,9 +197,13 @@ __global__ __launch_bounds__(256, (TPG == 25 ? 2 : 1)) void wgrad_kernel(const W
       for (int ks = 0; ks < KSR; ++ks) {
         uint4 A[MA];
         if constexpr (CPU == 8) {
-          const char* p = gl + (r * 32 + 8 * q + (l16 >> 2)) * k.pixbG + (l16 & 3) * 8;
+          // K (pixel) assignment inside a 32-pixel row: quad q takes pixels 4q..4q+3 (low half) and 16+4q..16+4q+3 (high half),
+          // the same for both operands.  A 32-lane half of a ds_read_b64_tr_b16 then covers 8 CONSECUTIVE pixels, which with a
+          // pixel stride of 32*odd bytes is conflict-free; round 1's "8q + {0..3}, +4" assignment (pixels {0-3, 8-11} per half)
+          // is a 2-way bank conflict for every stride (tools/lds_banks.py).
+          const char* p = gl + (r * 32 + 4 * q + (l16 >> 2)) * k.pixbG + (l16 & 3) * 8;
 #pragma unroll
-          for (int a = 0; a < MA; ++a) A[a] = tr_frag16(p + a * 32, 4 * k.pixbG);
+          for (int a = 0; a < MA; ++a) A[a] = tr_frag16(p + a * 32, 16 * k.pixbG);
         } else {
           const char* p = gl + (r * 32 + ks * 16 + 4 * q) * k.pixbG + l16 * 4;
 #pragma unroll
@@ -208,7 +212,7 @@ __global__ __launch_bounds__(256, (TPG == 25 ? 2 : 1)) void wgrad_kernel(const W
         // this lane's LDS offset inside row r; kept opaque so that the compiler adds the (scalar) tap offset at each
         // read instead of hoisting one address register per tap out of the row loop (50 VGPRs for 25 taps)
         int xrow;
-        if constexpr (CPU == 8) xrow = (r * k.S * k.HW + (8 * q + (l16 >> 2)) * k.S) * k.pixbX + (l16 & 3) * 8;
+        if constexpr (CPU == 8) xrow = (r * k.S * k.HW + (4 * q + (l16 >> 2)) * k.S) * k.pixbX + (l16 & 3) * 8;
         else xrow = (r * k.S * k.HW + (ks * 16 + 4 * q) * k.S) * k.pixbX + l16 * 4;
         asm volatile("" : "+v"(xrow));
         // Taps beyond ntaps (toff = 0) are computed and discarded: no branch.  The taps go in chunks of TC: all of a
@@ -223,7 +227,7 @@ __global__ __launch_bounds__(256, (TPG == 25 ? 2 : 1)) void wgrad_kernel(const W
 #pragma unroll
             for (int b = 0; b < NBW; ++b) {
               if constexpr (CPU == 8) {
-                B[tt][b] = tr_frag16(xl + (xrow + toff[tc + tt] + (nb0 + b) * 32), 4 * k.S * k.pixbX);
+                B[tt][b] = tr_frag16(xl + (xrow + toff[tc + tt] + (nb0 + b) * 32), 16 * k.S * k.pixbX);
               } else {
                 B[tt][b] = sc_frag32(xl + (xrow + toff[tc + tt] + (nb0 + b) * 64), k.S * k.pixbX);
               }
@@ -341,6 +345,13 @@ static int wgrad_plan(const ubr_wgrad_desc* d, WPlan* p) {
   p->MA = MA; p->NB = NB; p->TPG = TPG;
   p->pixbG = MA * 16 * esz + 16;
   p->pixbX = NB * 16 * esz + 16;
+  if (esz == 2) {
+    // conflict-free strides of the transposed fragment reads (see wgrad_kernel): 32 * odd bytes where consecutive K pixels are
+    // one pixel apart (the gradient tile, and the input tile at stride 1); the padded stride already is conflict-free at stride 2
+    auto odd32 = [](int bytes) { int k = (bytes + 31) / 32; if (k % 2 == 0) ++k; return 32 * k; };
+    p->pixbG = odd32(MA * 32);
+    if (d->S == 1) p->pixbX = odd32(NB * 32);
+  }
   size_t gbytes = (size_t)p->TH * 32 * p->pixbG;
   gbytes = (gbytes + 15) & ~(size_t)15;
   p->x_off = (int)gbytes;
