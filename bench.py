@@ -66,14 +66,65 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("UBR_CPU_THREADS", str(n)))))
 
 
-def cpu_baseline(size, inplanes, seconds_budget=20.0):
+def _trained_iou(size, inplanes, steps=200):
+    """BASELINE's second metric on weights that mean something: train the HIP path for `steps` bf16 steps on synthetic crops
+    (about 3 s), copy the weights to the CPU oracle, and compare class maps on a held-out batch (eval mode, the deployment
+    semantics): per-class pixel IoU of the fp32 and bf16 HIP forward against the CPU reference path, plus the trained
+    network's own IoU against the labels (so the reader can see it did learn)."""
+    from oracle import uresnet_oracle as O
+    from ubresnet_amd import synthetic
+    from ubresnet_amd.models.ub_uresnet import UResNet
+    from ubresnet_amd.optim import FlatAdam
+    from ubresnet_amd.training.pixelwise_nllloss import PixelWiseNLLLoss
+    torch.manual_seed(99)
+    m = UResNet(num_classes=3, input_channels=1, inplanes=inplanes).cuda().train()
+    m.compute_dtype = torch.bfloat16
+    opt = FlatAdam(m, lr=1e-3, weight_decay=1e-4)
+    crit = PixelWiseNLLLoss()
+    B = 8
+    pool = [tuple(torch.from_numpy(a).cuda() for a in synthetic.make_batch(B, size, size, 7000 + 100 * i)) for i in range(4)]
+    first = last = None
+    for i in range(steps):
+        x, lab, wgt = pool[i % len(pool)]
+        loss = crit(m(x), lab, wgt)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        if i == 0:
+            first = float(loss)
+    last = float(loss)
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    xh, labh, _ = synthetic.make_batch(2, size, size, 9000)
+    xt = torch.from_numpy(xh)
+    with torch.no_grad():
+        ref = O.uresnet_forward(sd, xt, False)
+        a = ref.argmax(1).reshape(-1)
+        top2 = torch.topk(ref, 2, dim=1)[0]
+        safe = ((top2[:, 0] - top2[:, 1]) > 0.2).reshape(-1)
+        out = {"train_steps": steps, "loss_first": first, "loss_last": last, "pixels": int(a.numel()),
+               "margin_gt_0.2_fraction": float(safe.float().mean())}
+        lab = torch.from_numpy(labh).reshape(-1)
+        cm = torch.bincount(lab * 3 + a, minlength=9).reshape(3, 3)
+        out["reference_vs_labels"] = [float(v) for v in O.iou_from_confusion(cm)]
+        m.eval()
+        for name, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+            m.compute_dtype = dt
+            b = m(xt.cuda()).argmax(1).reshape(-1).cpu()
+            for tag, sel in (("", slice(None)), ("_margin_gt_0.2", safe)):
+                cm = torch.bincount(a[sel] * 3 + b[sel], minlength=9).reshape(3, 3)
+                out[name + tag] = [float(v) for v in O.iou_from_confusion(cm)]
+    del m, opt
+    return out
+
+
+def cpu_baseline(size, inplanes, seconds_budget=12.0):
     """The CPU oracle (validated against the reference's own code, tests/test_oracle_golden.py)
-    doing the same train step on the host cores: BASELINE config 0 (batch 2, fp32)."""
+    doing the same train step on the host cores: BASELINE config 0 (batch 2, fp32); timed with all host cores the box
+    gives this job and with 8 threads (comparable with the survey's 1.32 img/s)."""
     from collections import OrderedDict
     from oracle import uresnet_oracle as O
     from ubresnet_amd import synthetic
     cores = host_cores()
-    torch.set_num_threads(cores)
     B = 2
     sd = O.seeded_state_dict(O.uresnet_schema(3, 1, inplanes, 16), 42)
     x, lab, wgt = synthetic.make_batch(B, size, size, 1000)
@@ -97,6 +148,7 @@ def cpu_baseline(size, inplanes, seconds_budget=20.0):
     iou = None
     try:
         from ubresnet_amd.models.ub_uresnet import UResNet
+        torch.set_num_threads(cores)
         with torch.no_grad():
             ref = O.uresnet_forward(p, xt, True, {})
             m = UResNet(num_classes=3, input_channels=1, inplanes=inplanes)
@@ -105,7 +157,7 @@ def cpu_baseline(size, inplanes, seconds_budget=20.0):
             a = ref.argmax(1).reshape(-1)
             top2 = torch.topk(ref, 2, dim=1)[0]
             safe = ((top2[:, 0] - top2[:, 1]) > 0.2).reshape(-1)
-            iou = {"pixels": int(a.numel()), "margin_gt_0.2_fraction": float(safe.float().mean())}
+            iou = {"weights": "seeded, untrained", "pixels": int(a.numel()), "margin_gt_0.2_fraction": float(safe.float().mean())}
             for name, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
                 m.compute_dtype = dt
                 b = m(xt.cuda()).argmax(1).reshape(-1).cpu()
@@ -115,20 +167,32 @@ def cpu_baseline(size, inplanes, seconds_budget=20.0):
             del m
     except Exception as e:     # the IoU report must never take the benchmark line down
         iou = {"error": repr(e)}
+    try:
+        iou_trained = _trained_iou(size, inplanes)
+    except Exception as e:
+        iou_trained = {"error": repr(e)}
 
-    tw = time.time()
-    step()
-    tw = time.time() - tw
-    nmax = max(1, min(12, int(seconds_budget / max(tw, 1e-3))))
-    t0 = time.time()
-    n = 0
-    while n < nmax:
+    def timed(nthreads, budget):
+        torch.set_num_threads(nthreads)
+        tw = time.time()
         step()
-        n += 1
-    el = time.time() - t0
-    return {"value": B * n / el, "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": "%d timed train steps (1 warm-up) of the CPU oracle, UResNet ip%d fp32, batch %d, %dx%d, Adam" % (n, inplanes, B, size, size),
-            "ms_per_step": 1e3 * el / n, "iou_vs_reference": iou}
+        tw = time.time() - tw
+        nmax = max(2, min(12, int(budget / max(tw, 1e-3))))
+        ts = []
+        for _ in range(nmax):
+            t0 = time.time()
+            step()
+            ts.append(time.time() - t0)
+        return nmax, sum(ts) / len(ts), min(ts)
+
+    n, mean_s, min_s = timed(cores, seconds_budget)
+    res = {"value": B / mean_s, "unit": "images/sec", "cores": cores, "kind": "port",
+           "sample": "%d timed train steps (1 warm-up) of the CPU oracle, UResNet ip%d fp32, batch %d, %dx%d, Adam" % (n, inplanes, B, size, size),
+           "ms_per_step": 1e3 * mean_s, "ms_per_step_min": 1e3 * min_s, "iou_vs_reference": iou, "iou_vs_reference_trained": iou_trained}
+    if cores != 8:
+        n8, mean8, min8 = timed(min(8, cores), seconds_budget / 2)
+        res["threads_8"] = {"value": B / mean8, "ms_per_step": 1e3 * mean8, "ms_per_step_min": 1e3 * min8, "steps": n8}
+    return res
 
 
 def infer_leg(events=6, warmup=2):
@@ -280,7 +344,7 @@ def main():
         mfma_bound = ai > peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9)
         traffic = None
         try:   # HBM bytes per launch from a committed rocprofv3 --pmc collection of this command (profiles/), if present
-            pm = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
+            pm = json.load(open(os.path.join(REPO, "profiles", "r02_pmc_traffic.json")))
             if pm.get("dtype") == a.dtype and pm.get("batch") == a.batch and sym in pm.get("kernels", {}):
                 traffic = pm["kernels"][sym]["hbm_bytes_per_launch"]
         except Exception:
@@ -294,6 +358,29 @@ def main():
         res["roofline"].update({"kernel": sym, "launches_per_step": cnt, "avg_launch_us": 1e6 * tsum / cnt,
                                 "algorithmic_bytes_per_launch": nbytes / cnt, "algorithmic_flop_per_launch": flops / cnt,
                                 "arithmetic_intensity": ai, "share_of_gpu_time": tsum / tot})
+        # the same figures for the next kernels by time, and for the layer round 1's review named (the full-resolution
+        # 16->16 3x3 convolutions: 268 MB of algorithmic traffic per launch)
+        ridge = peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9)
+        tops = []
+        for sy, (c_, t_, b_, fl_) in sorted(bysym.items(), key=lambda kv: -kv[1][1])[:8]:
+            mf = fl_ / max(b_, 1) > ridge
+            ach_ = fl_ / t_ / 1e12 if mf else b_ / t_ / 1e9
+            pk_ = peak_tf if mf else HBM_PEAK_GBS
+            tops.append({"kernel": sy, "launches_per_step": c_, "avg_launch_us": 1e6 * t_ / c_, "bound": "mfma" if mf else "hbm",
+                         "achieved": ach_, "unit": "TFLOP/s" if mf else "GB/s", "frac": ach_ / pk_, "share_of_gpu_time": t_ / tot})
+        res["roofline_top_kernels"] = tops
+        if a.model == "uresnet":
+            want = "%dx%dx%dx%d" % (a.batch, a.size, a.size, a.inplanes)
+            agg = [0, 0.0, 0]
+            for (nm, sg), (c_, t_, b_, fl_) in prof.summary(by="shape").items():
+                parts = sg.split(" ")
+                if nm == "conv" and "taps9" in parts and parts[0] == want and parts[2] == want and "S2" not in parts:
+                    agg[0] += c_; agg[1] += t_; agg[2] += b_
+            if agg[0]:
+                res["roofline_fullres_3x3_conv"] = {"layer": "3x3 %d->%d at %dx%d, batch %d (forward and data-gradient launches)" % (a.inplanes, a.inplanes, a.size, a.size, a.batch),
+                                                    "launches_per_step": agg[0], "avg_launch_us": 1e6 * agg[1] / agg[0], "bound": "hbm", "achieved": agg[2] / agg[1] / 1e9,
+                                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": agg[2] / agg[1] / 1e9 / HBM_PEAK_GBS,
+                                                    "algorithmic_bytes_per_launch": agg[2] / agg[0]}
         res["kernel_time_ms_per_step"] = 1e3 * tot
         if a.breakdown_file:
             with open(a.breakdown_file, "w") as f:

@@ -103,6 +103,8 @@ int ubr_conv(const ubr_conv_desc* d, void* stream);
 /* tile configuration (FW, NT, TWF, PIPE = template arguments of conv_igemm_kernel) chosen by this thread's last
  * ubr_conv call: lets host-side timing be keyed by kernel symbol, as rocprofv3 reports it */
 void ubr_conv_last_config(int* fw, int* nt, int* twf, int* pipe);
+/* kernel symbol (as rocprofv3 --kernel-trace names it) of this thread's last ubr_conv launch, for host-side timing tables */
+int ubr_conv_last_kernel(char* buf, int n);
 
 /* Weight repack: fp32 master weights (PyTorch layouts) -> packed image for ubr_conv.
  *   dst[t][ku][m][e] = (T) src[m*sm + (ku*CPU+e)*sk + tapidx[t]],  m < M (zero for M <= m < Mpad)

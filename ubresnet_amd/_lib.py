@@ -83,7 +83,7 @@ class WgradDesc(C.Structure):
 
 # every symbol include/ubresnet_hip.h declares (tests check that all of them are exported)
 SYMBOLS = [
-    "ubr_conv", "ubr_conv_last_config", "ubr_pack_weights", "ubr_pack_weights_batched", "ubr_bn_fold_batched", "ubr_wgrad_plan", "ubr_wgrad", "ubr_wgrad_last_config", "ubr_wgrad_reduce",
+    "ubr_conv", "ubr_conv_last_config", "ubr_conv_last_kernel", "ubr_pack_weights", "ubr_pack_weights_batched", "ubr_bn_fold_batched", "ubr_wgrad_plan", "ubr_wgrad", "ubr_wgrad_last_config", "ubr_wgrad_reduce",
     "ubr_stem_forward", "ubr_stem_wgrad", "ubr_stem_wgrad_workspace", "ubr_stem_expand",
     "ubr_bn_finalize", "ubr_bn_eval_affine", "ubr_bn_bwd_reduce", "ubr_bn_bwd_finalize", "ubr_bn_bwd_apply",
     "ubr_block_tail_fwd", "ubr_block_tail_bwd_reduce", "ubr_block_tail_bwd_apply",
@@ -106,6 +106,7 @@ def _declare(lib):
     lib.ubr_stem_wgrad_workspace.argtypes = [i32] * 5
     lib.ubr_conv.argtypes = [C.POINTER(ConvDesc), vp]
     lib.ubr_conv_last_config.argtypes = [C.POINTER(C.c_int)] * 4
+    lib.ubr_conv_last_kernel.argtypes = [C.c_char_p, i32]
     lib.ubr_conv_last_config.restype = None
     lib.ubr_wgrad_last_config.argtypes = [C.POINTER(C.c_int)] * 5
     lib.ubr_wgrad_last_config.restype = None

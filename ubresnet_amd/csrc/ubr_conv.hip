@@ -1104,7 +1104,8 @@ __global__ __launch_bounds__(256, 1) void conv_wide_kernel(const ConvK k) {
   }
 }
 
-static thread_local int g_last_conv_cfg[4] = {0, 0, 0, 0};   // FW, NT, TWF, PIPE of this thread's last launch
+static thread_local int g_last_conv_cfg[4] = {0, 0, 0, 0};   // FW, NT, TWF, kind (0 generic, 1 cin-block pipeline, 2 thin, 3 wide) of this thread's last launch
+static thread_local char g_last_conv_name[160] = "";         // kernel symbol of that launch, as rocprofv3 prints it
 struct TileCfg { int FW, NT, TWF; };
 // id -> config; keep in sync with the dispatch switch
 static const TileCfg kCfgs[] = {
@@ -1206,6 +1207,8 @@ int try_thin(const ConvK& c, dim3 grid, hipStream_t st, int* rc) {
   if (g.x > cap && cap > 0) g.x = cap;
   g_last_conv_cfg[3] = 2;
   const bool xf = c.in_scale != nullptr;
+  snprintf(g_last_conv_name, sizeof(g_last_conv_name), "conv_thin_kernel<%s, %d, %d, %d, %d, %s, %s>", sizeof(T) == 4 ? "float" : (std::is_same<T, bf16_t>::value ? "bf16_t" : "f16_t"),
+           FW, NT, TWF, c.UPB, xf ? "true" : "false", c.epilogue == 1 ? "true" : "false");
   if (c.epilogue == 1) {
     // conv11 + LogSoftmax (models/ub_uresnet.py:64,143): 7x7 over 16 channels, the 8x32-pixel tile
     if constexpr (FW == 4 && NT == 1) {
@@ -1346,6 +1349,12 @@ static bool plan_wide(const ubr_conv_desc* d, int wi, int dymin, int dymax, int 
 }
 
 }  // namespace
+
+extern "C" int ubr_conv_last_kernel(char* buf, int n) {
+  if (buf == nullptr || n <= 0) return UBR_EINVAL;
+  snprintf(buf, (size_t)n, "%s", g_last_conv_name);
+  return UBR_OK;
+}
 
 extern "C" void ubr_conv_last_config(int* fw, int* nt, int* twf, int* pipe) {
   if (fw) *fw = g_last_conv_cfg[0];
@@ -1520,10 +1529,20 @@ extern "C" int ubr_conv(const ubr_conv_desc* d, void* stream) {
       fprintf(stderr, "ubr_conv plan: N%d %dx%d Cin%d Cout%d taps%d S%d | cfg%d (%d,%d,%d) UPB%d nblk%d lds %zu wgs %u x %u\n", d->N, d->OH, d->OW,
               d->Cin, d->Cout, d->ntaps, d->S, best.cfg, c.FW, c.NT, c.TWF, best.UPB, k.nblk, best.lds, grid.x, grid.y);
   }
-  switch (d->dtype) {
-    case UBR_F32: return launch_T<float>(best.cfg, k, grid, best.lds, st);
-    case UBR_BF16: return launch_T<bf16_t>(best.cfg, k, grid, best.lds, st);
-    default: return launch_T<f16_t>(best.cfg, k, grid, best.lds, st);
+  {
+    const char* tn = d->dtype == UBR_F32 ? "float" : (d->dtype == UBR_BF16 ? "bf16_t" : "f16_t");
+    g_last_conv_name[0] = 0;
+    int rc;
+    switch (d->dtype) {
+      case UBR_F32: rc = launch_T<float>(best.cfg, k, grid, best.lds, st); break;
+      case UBR_BF16: rc = launch_T<bf16_t>(best.cfg, k, grid, best.lds, st); break;
+      default: rc = launch_T<f16_t>(best.cfg, k, grid, best.lds, st); break;
+    }
+    if (g_last_conv_name[0] == 0) {     // (the thin path names itself)
+      if (best.cfg >= 100) { const WideCfg& w = kWide[best.cfg - 100]; snprintf(g_last_conv_name, sizeof(g_last_conv_name), "conv_wide_kernel<%s, %d, %d, %d, %d>", tn, w.FW, w.NT, w.TWF, w.WN); }
+      else snprintf(g_last_conv_name, sizeof(g_last_conv_name), "conv_igemm_kernel<%s, %d, %d, %d, %s>", tn, c.FW, c.NT, c.TWF, g_last_conv_cfg[3] == 1 ? "true" : "false");
+    }
+    return rc;
   }
 }
 

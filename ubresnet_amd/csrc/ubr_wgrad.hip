@@ -317,7 +317,8 @@ static int wgrad_plan(const ubr_wgrad_desc* d, WPlan* p) {
   p->nsplit_mode = 0;
   p->TH = d->S == 1 ? 8 : 4;   // rows beyond GH are zero-filled, so small grids stay correct
   if (TPG <= 9 && d->Cout % 64 == 0 && d->Cin % 64 == 0) {   // wide layers: 64 x 64 channel tile, waves split cin
-    MA = (TPG == 9) ? 2 : 4; NB = 4; p->nsplit_mode = 1;   // 9 taps: 32 x 64 tile keeps the kernel under 256 VGPRs (2 waves/SIMD)
+    static const int ma9 = [] { const char* e = getenv("UBR_WGRAD_MA9"); return e ? atoi(e) : 2; }();
+    MA = (TPG == 9) ? ma9 : 4; NB = 4; p->nsplit_mode = 1;   // 9 taps: 32 x 64 tile keeps the kernel under 256 VGPRs (2 waves/SIMD)
     p->TH = d->S == 1 ? 4 : 2;
   }
   {
@@ -403,7 +404,7 @@ int wdispatch(const WgK& k, const WPlan& p, hipStream_t st) {
   }
 #define UBR_WCASE(ma, nb, tpg) if (!p.bigx && !p.nsplit_mode && p.MA == ma && p.NB == nb && p.TPG == tpg) return wlaunch<T, ma, nb, tpg, false>(k, p, st);
 #define UBR_NCASE(ma, tpg) if (!p.bigx && p.nsplit_mode && p.MA == ma && p.NB == 4 && p.TPG == tpg) return wlaunch<T, ma, 4, tpg, true>(k, p, st);
-  UBR_NCASE(4, 1) UBR_NCASE(4, 4) UBR_NCASE(2, 9)
+  UBR_NCASE(4, 1) UBR_NCASE(4, 4) UBR_NCASE(2, 9) UBR_NCASE(4, 9)
 #undef UBR_NCASE
   UBR_WCASE(1, 1, 1) UBR_WCASE(1, 2, 1) UBR_WCASE(2, 1, 1) UBR_WCASE(2, 2, 1)
   UBR_WCASE(1, 1, 4) UBR_WCASE(1, 2, 4) UBR_WCASE(2, 1, 4) UBR_WCASE(2, 2, 4)

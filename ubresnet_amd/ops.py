@@ -74,9 +74,9 @@ def _timed(name):
                 cout = args[4]
                 npix = y.shape[0] * (y.shape[2] * y.shape[3] if y.shape[1] == cout and y.dtype == torch.float32 and kwargs.get("logsoftmax") else y.shape[1] * y.shape[2])
                 flops = 2.0 * npix * x.shape[3] * cout * ntaps
-                a, b, c, pp = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
-                L.lib().ubr_conv_last_config(C.byref(a), C.byref(b), C.byref(c), C.byref(pp))
-                kern = "conv_igemm_kernel<%s, %d, %d, %d, %s>" % (_DT_NAME[x.dtype], a.value, b.value, c.value, "true" if pp.value else "false")
+                buf = C.create_string_buffer(160)
+                L.lib().ubr_conv_last_kernel(buf, 160)
+                kern = buf.value.decode()
             _prof.records.append((name, kern, sig, _act_bytes(acts), flops, e0, e1))
             return r
         wrapper.__name__ = fn.__name__
