@@ -37,6 +37,18 @@ if what.startswith("conv"):
     stats = st if "nostats" not in sys.argv else None
     hint = max([int(a[4:]) for a in sys.argv if a.startswith("hint")] + [0])
     ctaps = ops.conv_taps(k, 1, k // 2)
+    stamps = torch.zeros(16 * 8192, dtype=torch.int64, device=dev)
+    os.environ["UBR_CONV_STAMP_PTR"] = str(stamps.data_ptr())     # read once by a -DUBR_CONV_STAMPS build
+    import atexit
+    def _dump():
+        st = stamps.cpu().view(-1, 16)
+        st = st[st[:, 4] > 0]
+        if len(st):
+            m = st.float().median(0).values
+            print("   prologue %d, main loop %d, epilogue %d cycles (medians)" % ((st[:, 5] - st[:, 7]).float().median(), (st[:, 8] - st[:, 5]).float().median(), (st[:, 9] - st[:, 8]).float().median()))
+            print("stamps (median cycles of wave 0 per workgroup, %d WGs): barriers %d, load wait %d, transform+LDS store %d, load issue %d, mfma loop %d, total before epilogue %d"
+                  % (len(st), m[3], m[6], m[0], m[1], m[2], m[4]))
+    atexit.register(_dump)
     fn = lambda: ops.conv(x, wp, y, ctaps, Cout, xf=xf, stats=stats, tile_hint=hint)
     nbytes = x.numel() * 2 + y.numel() * 2
     flops = 2.0 * N * HW * HW * Cin * Cout * k * k
@@ -47,7 +59,31 @@ elif what.startswith("wgrad"):
     ws = ops.WgradWorkspace()
     xfw = aff(Cin)
     taps = ops.conv_taps(k, 1, k // 2)
-    fn = lambda: ops.wgrad(x, g, taps, dW, Cin * k * k, k * k, Cout, Cin, ws, xf=xfw)
+    if "kernelonly" in sys.argv:      # time ubr_wgrad alone (no slab reduction)
+        import ctypes as C
+        from ubresnet_amd import _lib as L
+        d = L.WgradDesc(); d.dtype = L.dtype_id(dt); d.N, d.H, d.W, d.Cin = N, HW, HW, Cin
+        d.x = ops._tv(x); d.xf = ops._xf(xfw); d.GH, d.GW, d.Cout = HW, HW, Cout; d.g = ops._tv(g); d.ntaps = len(taps)
+        for i, t in enumerate(taps): d.dy[i], d.dx[i] = t[0], t[1]
+        d.S, d.iy0, d.ix0 = 1, 0, 0
+        ns, nb = C.c_int32(0), C.c_int64(0)
+        L.check(L.lib().ubr_wgrad_plan(C.byref(d), C.byref(ns), C.byref(nb)), "plan")
+        slabs = torch.empty(nb.value // 4 + 16, device=dev); d.slabs = slabs.data_ptr(); d.nsplit = ns.value
+        print("nsplit", ns.value, "slab MB", nb.value / 1e6)
+        stamps = torch.zeros(8 * 4096, dtype=torch.int64, device=dev)
+        os.environ["UBR_WGRAD_STAMP_PTR"] = str(stamps.data_ptr())     # read once by a -DUBR_WGRAD_STAMPS build
+        fn = lambda: L.check(L.lib().ubr_wgrad(C.byref(d), L.stream_ptr()), "wgrad")
+        import atexit
+        def _dump():
+            st = stamps.cpu().view(-1, 8)
+            st = st[st[:, 4] > 0]
+            if len(st):
+                m = st.float().median(0).values
+                print("stamps (median cycles per workgroup over %d WGs): store+barriers %d, load issue %d, compute %d, epilogue %d, total %d; start spread %d"
+                      % (len(st), m[0], m[1], m[2], m[3], m[4], int(st[:, 5].max() - st[:, 5].min())))
+        atexit.register(_dump)
+    else:
+        fn = lambda: ops.wgrad(x, g, taps, dW, Cin * k * k, k * k, Cout, Cin, ws, xf=xfw)
     nbytes = x.numel() * 2 + g.numel() * 2
     flops = 2.0 * N * HW * HW * Cin * Cout * k * k
 else:

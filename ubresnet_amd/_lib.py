@@ -13,7 +13,7 @@ import threading
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libubresnet_hip.so")
+LIB_PATH = os.environ.get("UBR_LIB", os.path.join(HERE, "libubresnet_hip.so"))     # UBR_LIB: A/B builds of the same ABI (tools)
 
 F32, BF16, F16 = 0, 1, 2
 MAX_TAPS = 64

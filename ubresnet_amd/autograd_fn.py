@@ -19,8 +19,8 @@ def compute_dtype(model) -> torch.dtype:
     dt = getattr(model, "compute_dtype", None)
     if dt is not None:
         return dt
-    if torch.is_autocast_enabled():
-        return torch.get_autocast_gpu_dtype()
+    if torch.is_autocast_enabled("cuda"):
+        return torch.get_autocast_dtype("cuda")
     return torch.float32
 
 

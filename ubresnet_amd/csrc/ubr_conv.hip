@@ -38,10 +38,11 @@ struct ConvK {
   unsigned rw, rw_magic;                         // items per halo row and ceil(2^32/rw)
   int x_sy32, x_sx32;                            // input row / pixel strides in bytes (per-image offsets fit 31 bits)
   int step_j, step_hy, step_goff, wrap_goff;     // halo walk: advance of (column item, row, byte offset) per 256 items
-  int wl_off, halo_off, red_off;                 // LDS carve offsets
+  int wl_off, halo_off, red_off, xfc_off;        // LDS carve offsets
   int epilogue, act, wide_store, dbg, wlinear, N;
   int8_t dy[UBR_MAX_TAPS], dx[UBR_MAX_TAPS];
   uint8_t wt[UBR_MAX_TAPS];
+  unsigned long long* stamps;                    // diagnostic build (-DUBR_CONV_STAMPS): per-workgroup phase cycle sums
 };
 
 template <typename T> __device__ __forceinline__ void store4(char* p, const float* v);
@@ -83,6 +84,8 @@ __host__ __device__ constexpr int conv_pixb(int upb) { return upb == 2 ? 32 : up
 __host__ __device__ constexpr int conv_pipe_hslots(int fw, int twf) { return ((4 * fw / twf + 2) * (twf * 16 + 2) * 4 + 255) / 256; }
 __host__ __device__ constexpr int conv_pipe_wslots(int nt) { return (36 * nt * 16 + 255) / 256; }
 
+typedef __attribute__((ext_vector_type(4))) unsigned ubr_u4;
+
 template <typename T, int FW, int NT, int TWF, bool PIPE>
 __global__ __launch_bounds__(256, ((NT == 4 && FW <= 2 && !PIPE) ? 4 : 2)) void conv_igemm_kernel(const ConvK k) {
   constexpr int TN = NT * 16;
@@ -99,6 +102,9 @@ __global__ __launch_bounds__(256, ((NT == 4 && FW <= 2 && !PIPE) ? 4 : 2)) void 
   char* halo = smem + k.halo_off;
   float* red = reinterpret_cast<float*>(smem + k.red_off);
 
+#ifdef UBR_CONV_STAMPS
+  const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+#endif
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, l16 = lane & 15;
   int t = blockIdx.x;
   const int tx = t % k.tiles_x; t /= k.tiles_x;
@@ -150,71 +156,118 @@ __global__ __launch_bounds__(256, ((NT == 4 && FW <= 2 && !PIPE) ? 4 : 2)) void 
     // Cin-block pipeline (wide layers, >= 2 cin blocks): the global loads of block b+1 (halo and weight slab) are
     // issued into registers right before the MFMA phase of block b and written to LDS after it, so a block's load
     // round trip hides under the previous block's matrix work instead of being waited for at the top of each block.
+    //
+    // With two workgroups per CU a SIMD holds two waves, and everything that is not an MFMA is issue-bound (in-kernel
+    // cycle stamps, 16x32x32x256 -> 256: of 58.7 k cycles per workgroup 23.7 k were the MFMA loop, 15.1 k the ISSUE of 15
+    // guarded loads per block, 17.2 k the BatchNorm transform + LDS stores, 0.07 k waiting for data).  So the per-block
+    // bookkeeping is done ONCE per workgroup: a slot's source offset (buffer load, out-of-range = zero padding), its
+    // validity bit and its LDS address do not depend on the cin block; the block only moves a scalar offset.
     constexpr int HS = conv_pipe_hslots(FW, TWF), WS = conv_pipe_wslots(NT);
-    uint4 hv[HS], wv[WS];
-    unsigned hok = 0u;
+    constexpr int kOOR = (int)0x80000000;        // beyond any num_records: the load returns zeros
+    ubr_u4 hv[HS], wv[WS];
     const int c = tid & (k.UPB - 1);
-    const int hy00 = (int)__umulhi((unsigned)tid, k.rw_magic);
-    const int j00 = tid - hy00 * (int)k.rw;
     const int nw = 4 * k.steps * TN;
-    auto load_blk = [&](int blk) {
-      const int ch0 = (blk * k.UPB + c) * CPU;
-      const char* xc = xn + (long)ch0 * ESZ;
-      int hy = hy00, j = j00;
-      int goff = (hy0 + hy) * k.x_sy32 + (hx0 + (j >> k.lgUPB)) * k.x_sx32;
-      hok = 0u;
+    int hoff[HS], woff[WS];
+    unsigned hok = 0u;
+    {
+      int hy = (int)__umulhi((unsigned)tid, k.rw_magic);
+      int j = tid - hy * (int)k.rw;
 #pragma unroll
       for (int u = 0; u < HS; ++u) {
         const int iy = hy0 + hy, ix = hx0 + (j >> k.lgUPB);
         const bool ok = (tid + u * 256 < nitems) && (unsigned)iy < (unsigned)k.H && (unsigned)ix < (unsigned)k.W;
-        hv[u] = make_uint4(0u, 0u, 0u, 0u);
-        if (ok) { hv[u] = ldg16(xc + goff); hok |= 1u << u; }
-        j += k.step_j; hy += k.step_hy; goff += k.step_goff;
-        if (j >= (int)k.rw) { j -= (int)k.rw; hy += 1; goff += k.wrap_goff; }
+        hoff[u] = ok ? iy * k.x_sy32 + ix * k.x_sx32 + c * 16 : kOOR;
+        hok |= ok ? (1u << u) : 0u;
+        j += k.step_j; hy += k.step_hy;
+        if (j >= (int)k.rw) { j -= (int)k.rw; hy += 1; }
       }
-      const int boff = blk * k.UPB * k.Cout_pad + n0;
 #pragma unroll
       for (int u = 0; u < WS; ++u) {
         const int i = tid + u * 256;
-        wv[u] = make_uint4(0u, 0u, 0u, 0u);
+        int v = kOOR;
         if (i < nw) {
           const int src = wsrc[i / TN];
-          if (src >= 0) wv[u] = ldg16(k.w + ((long)(src + boff + (i % TN))) * 16);
+          if (src >= 0) v = (src + n0 + (i % TN)) * 16;
         }
+        woff[u] = v;
       }
+    }
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)xn, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)k.w, 0, 0x7fffffff, 0x00020000);
+    // BatchNorm constants of every input channel, [unit][sub | scale | shift | lo][CPU] in LDS: a thread's block constants are
+    // 4 * CPU consecutive floats
+    float* xfc = reinterpret_cast<float*>(smem + k.xfc_off);
+    if (has_xf) {
+      for (int ch = tid; ch < k.CU * CPU; ch += 256) {
+        float* o = xfc + (ch / CPU) * 4 * CPU + (ch % CPU);
+        o[0] = k.in_sub[ch]; o[CPU] = k.in_scale[ch]; o[2 * CPU] = k.in_shift[ch]; o[3 * CPU] = k.in_lo[ch];
+      }
+    }
+    auto load_blk = [&](int blk) {
+      const int sh = blk * k.UPB * 16, sw = blk * k.UPB * k.Cout_pad * 16;
+#pragma unroll
+      for (int u = 0; u < HS; ++u) hv[u] = __builtin_amdgcn_raw_buffer_load_b128(xr, hoff[u], sh, 0);
+#pragma unroll
+      for (int u = 0; u < WS; ++u) wv[u] = __builtin_amdgcn_raw_buffer_load_b128(wr, woff[u], sw, 0);
     };
+    // complete slots (every thread has an item) / the partial one: wave-uniform tests in front of the LDS writes
+    const int hfull = nitems >> 8, hrem = nitems & 255, wfull = nw >> 8, wrem = nw & 255;
+    char* const halo_w = halo + (tid >> k.lgUPB) * k.pixb + c * 16;
+    const int halo_inc = (256 >> k.lgUPB) * k.pixb;
+    char* const wl_w = wl + tid * 16;
     auto store_blk = [&](int blk) {
-      const int ch0 = (blk * k.UPB + c) * CPU;
+#pragma unroll
+      for (int u = 0; u < WS; ++u)
+        if (u < wfull || (u == wfull && tid < wrem)) *reinterpret_cast<ubr_u4*>(wl_w + u * 4096) = wv[u];
       float xsub[CPU], xsc[CPU], xsh[CPU], xlo[CPU];
       if (has_xf) {
+        const float4* cp = reinterpret_cast<const float4*>(xfc + (blk * k.UPB + c) * 4 * CPU);
 #pragma unroll
-        for (int e = 0; e < CPU; ++e) { xsub[e] = k.in_sub[ch0 + e]; xsc[e] = k.in_scale[ch0 + e]; xsh[e] = k.in_shift[ch0 + e]; xlo[e] = k.in_lo[ch0 + e]; }
+        for (int e = 0; e < CPU; e += 4) {
+          const float4 a = cp[e / 4], b = cp[(CPU + e) / 4], cc = cp[(2 * CPU + e) / 4], d = cp[(3 * CPU + e) / 4];
+          xsub[e] = a.x; xsub[e + 1] = a.y; xsub[e + 2] = a.z; xsub[e + 3] = a.w;
+          xsc[e] = b.x; xsc[e + 1] = b.y; xsc[e + 2] = b.z; xsc[e + 3] = b.w;
+          xsh[e] = cc.x; xsh[e + 1] = cc.y; xsh[e + 2] = cc.z; xsh[e + 3] = cc.w;
+          xlo[e] = d.x; xlo[e + 1] = d.y; xlo[e + 2] = d.z; xlo[e + 3] = d.w;
+        }
       }
 #pragma unroll
       for (int u = 0; u < HS; ++u) {
-        const int i = tid + u * 256;
-        uint4 v = hv[u];
-        if (has_xf && ((hok >> u) & 1u)) {
+        uint4 v = make_uint4(hv[u].x, hv[u].y, hv[u].z, hv[u].w);
+        if (has_xf) {
           float f[CPU];
           ET<T>::unpack(v, f);
 #pragma unroll
           for (int e = 0; e < CPU; ++e) f[e] = fmaxf(fmaf(f[e] - xsub[e], xsc[e], xsh[e]), xlo[e]);
-          v = ET<T>::pack(f);
+          const uint4 t4 = ET<T>::pack(f);
+          const bool ok = (hok >> u) & 1u;          // padding stays zero
+          v.x = ok ? t4.x : 0u; v.y = ok ? t4.y : 0u; v.z = ok ? t4.z : 0u; v.w = ok ? t4.w : 0u;
         }
-        if (i < nitems) *reinterpret_cast<uint4*>(halo + (i >> k.lgUPB) * k.pixb + c * 16) = v;
-      }
-#pragma unroll
-      for (int u = 0; u < WS; ++u) {
-        const int i = tid + u * 256;
-        if (i < nw) *reinterpret_cast<uint4*>(wl + (long)i * 16) = wv[u];
+        if (u < hfull || (u == hfull && tid < hrem)) *reinterpret_cast<uint4*>(halo_w + u * halo_inc) = v;
       }
     };
+#ifdef UBR_CONV_STAMPS
+    unsigned long long tS = 0, tL = 0, tC = 0, tB = 0, tW = 0, t_ = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_begin = t_;
+#define UBR_STAMP(acc_) do { unsigned long long n_ = __builtin_amdgcn_s_memtime(); acc_ += n_ - t_; t_ = n_; } while (0)
+#else
+#define UBR_STAMP(acc_) do { } while (0)
+#endif
     load_blk(0);
+    UBR_STAMP(tL);
     for (int blk = 0; blk < k.nblk; ++blk) {
-      if (blk) __syncthreads();          // previous block's fragments fully read
+      __syncthreads();          // previous block's fragments fully read (block 0: the constants above are visible)
+#ifdef UBR_CONV_STAMPS
+      UBR_STAMP(tB);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      UBR_STAMP(tW);
+#endif
       store_blk(blk);
+      UBR_STAMP(tS);
       __syncthreads();
+      UBR_STAMP(tB);
       if (blk + 1 < k.nblk) load_blk(blk + 1);
+      UBR_STAMP(tL);
       for (int s = 0; s < k.steps; ++s) {
         const int off = tbl[4 * s + q];
         uint4 wf[NT];
@@ -228,7 +281,14 @@ __global__ __launch_bounds__(256, ((NT == 4 && FW <= 2 && !PIPE) ? 4 : 2)) void 
           for (int j = 0; j < NT; ++j) acc[i][j] = mma_step<T>(acc[i][j], wf[j], a);
         }
       }
+      UBR_STAMP(tC);
     }
+#ifdef UBR_CONV_STAMPS
+    if (k.stamps != nullptr && tid == 0) {
+      unsigned long long* o = k.stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16;
+      o[0] = tS; o[1] = tL; o[2] = tC; o[3] = tB; o[6] = tW; o[4] = t_ - t_begin; o[5] = t_begin; o[7] = t_entry; o[8] = t_;
+    }
+#endif
   } else
   for (int blk = 0; blk < k.nblk; ++blk) {
     if (blk) __syncthreads();
@@ -413,6 +473,12 @@ __global__ __launch_bounds__(256, ((NT == 4 && FW <= 2 && !PIPE) ? 4 : 2)) void 
       }
     }
   }
+#ifdef UBR_CONV_STAMPS
+  if (PIPE && k.stamps != nullptr) {
+    __syncthreads();
+    if (tid == 0) k.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + 9] = __builtin_amdgcn_s_memtime();
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -473,7 +539,6 @@ template <typename T> __device__ __forceinline__ void store_frag_pair(char* p0, 
   }
 }
 
-typedef __attribute__((ext_vector_type(4))) unsigned ubr_u4;
 typedef __attribute__((ext_vector_type(2))) unsigned ubr_u2;
 
 struct ThinK {
@@ -1290,7 +1355,7 @@ int launch_T(int cfg, const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
   return UBR_EINVAL;
 }
 
-struct Plan { int cfg; size_t lds; int UPB, steps, HH, HW, pixb, wl_off, halo_off, red_off, tiles_x, tiles_y; };
+struct Plan { int cfg; size_t lds; int UPB, steps, HH, HW, pixb, wl_off, halo_off, red_off, xfc_off, tiles_x, tiles_y; };
 
 static bool plan_tile(const ubr_conv_desc* d, int cfg, int TH, int TW, int TN, int dymin, int dymax, int dxmin, int dxmax, Plan* p) {
   if (d->Cout_pad % TN) return false;
@@ -1313,6 +1378,8 @@ static bool plan_tile(const ubr_conv_desc* d, int cfg, int TH, int TW, int TN, i
   p->halo_off = (int)off; off += (size_t)HH * HW * pixb;
   off = (off + 15) & ~(size_t)15;
   p->red_off = (int)off; off += (size_t)4 * TN * 2 * sizeof(float);
+  p->xfc_off = (int)off;
+  if (d->xf.scale != nullptr && CU / UPB >= 2) off += (size_t)d->Cin * 4 * sizeof(float);   // cin-block pipeline: the layer's BatchNorm constants
   p->cfg = cfg; p->lds = off; p->UPB = UPB; p->steps = steps; p->HH = HH; p->HW = HW; p->pixb = pixb;
   p->tiles_x = ubr_cdiv(d->OW, TW); p->tiles_y = ubr_cdiv(d->OH, TH);
   if ((size_t)HH * HW * UPB >= 60000) return false;   // exact-division bound of the magic multiply
@@ -1505,7 +1572,7 @@ extern "C" int ubr_conv(const ubr_conv_desc* d, void* stream) {
   // moving step_j items right = (step_j / UPB) pixels (step_j is a multiple of UPB because rw and 256 are)
   k.step_goff = k.step_hy * k.x_sy32 + (k.step_j >> k.lgUPB) * k.x_sx32;
   k.wrap_goff = k.x_sy32 - best.HW * k.x_sx32;
-  k.wl_off = best.wl_off; k.halo_off = best.halo_off; k.red_off = best.red_off;
+  k.wl_off = best.wl_off; k.halo_off = best.halo_off; k.red_off = best.red_off; k.xfc_off = best.xfc_off;
   k.epilogue = d->epilogue; k.act = d->act; k.N = d->N;
   {
     bool nat = best.cfg < 100 && d->Cout_pad == kCfgs[best.cfg].NT * 16;
@@ -1513,6 +1580,7 @@ extern "C" int ubr_conv(const ubr_conv_desc* d, void* stream) {
     k.wlinear = nat ? 1 : 0;
   }
   { static const int dbg = [] { const char* e = getenv("UBR_CONV_DBG"); return e ? atoi(e) : 0; }(); k.dbg = dbg; }
+  { static const char* sp = getenv("UBR_CONV_STAMP_PTR"); k.stamps = sp ? (unsigned long long*)strtoull(sp, nullptr, 0) : nullptr; }
   k.wide_store = wide_ok ? 1 : 0;
   for (int t = 0; t < d->ntaps; ++t) { k.dy[t] = d->dy[t]; k.dx[t] = d->dx[t]; k.wt[t] = d->wt[t]; }
 

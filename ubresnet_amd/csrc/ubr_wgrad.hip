@@ -15,6 +15,9 @@
 #include <stdlib.h>
 #include "ubr_common.h"
 #include "ubr_host.h"
+#ifndef UBR_WGRAD_TC9
+#define UBR_WGRAD_TC9 1
+#endif
 
 namespace {
 
@@ -31,7 +34,8 @@ struct WgK {
   int pixbG, pixbX, x_off;
   unsigned hw_magic;                             // ceil(2^32 / HW)
   int x_sy32, x_sx32, g_sy32, g_sx32;            // row / pixel strides in bytes (per-image offsets fit 31 bits)
-  int n_cot;
+  int n_cot, dbg;
+  unsigned long long* stamps;     // diagnostic build (UBR_WGRAD_STAMPS): per-workgroup phase cycle sums
   int8_t dy[UBR_MAX_TAPS], dx[UBR_MAX_TAPS];
 };
 
@@ -107,8 +111,13 @@ __global__ __launch_bounds__(256, (TPG == 25 ? 2 : 1)) void wgrad_kernel(const W
   const int cx = tid % UX, px0 = tid / UX;
   constexpr int PXS_T = 256 / UX;
   const int npxG = k.TH * 32, npxX = k.HH * k.HW;
-  uint4 gv[GS], xv[XS];
-  unsigned xok = 0u;
+  // Tile loads run TWO tiles ahead (register sets A and B) where the kernel owns the whole register file (one wave per
+  // SIMD, every variant but the 25-tap one): with one workgroup per CU nothing else hides a load, and one tile's MFMA phase
+  // (72 MFMAs per wave, ~0.5 us) is shorter than a round trip to HBM under load -- the wide 9-tap kernel spent more time
+  // waiting for the next tile than computing.
+  constexpr bool DEEP = TPG != 25;
+  uint4 gvA[GS], xvA[XS], gvB[DEEP ? GS : 1], xvB[DEEP ? XS : 1];
+  unsigned xokA = 0u, xokB = 0u;
 
   // A thread's staging slots cover the same tile-relative pixels in every tile: their (row, col), bounds keys and
   // byte offsets relative to the tile origin are computed ONCE, so the per-tile work per 16-byte item is two
@@ -129,7 +138,7 @@ __global__ __launch_bounds__(256, (TPG == 25 ? 2 : 1)) void wgrad_kernel(const W
     x_rel[u] = hy * k.x_sy32 + hx * k.x_sx32;
   }
 
-  auto load_tile = [&](int tile) {
+  auto load_tile = [&](int tile, auto& gv, auto& xv, unsigned& xok) {
     int tt = tile;
     const int tx = tt % k.tiles_x; tt /= k.tiles_x;
     const int ty = tt % k.tiles_y;
@@ -141,7 +150,7 @@ __global__ __launch_bounds__(256, (TPG == 25 ? 2 : 1)) void wgrad_kernel(const W
     for (int u = 0; u < GS; ++u) {
       const int px = pg0 + u * PGS;
       gv[u] = make_uint4(0u, 0u, 0u, 0u);
-      if (px < npxG && (g_rc[u] >> 16) < gry && (g_rc[u] & 0xffff) < grx) gv[u] = ldg16(gn + g_rel[u]);
+      if (px < npxG && (g_rc[u] >> 16) < gry && (g_rc[u] & 0xffff) < grx && !(k.dbg & 1)) gv[u] = ldg16(gn + g_rel[u]);
     }
     const int hy0 = oy0 * k.S + k.iy0 + k.dymin, hx0 = ox0 * k.S + k.ix0 + k.dxmin;
     const char* xn = k.x + (long)n * k.x_sn + (long)(ci0 + cx * CPU) * ESZ + ((long)hy0 * k.x_sy32 + (long)hx0 * k.x_sx32);
@@ -152,14 +161,14 @@ __global__ __launch_bounds__(256, (TPG == 25 ? 2 : 1)) void wgrad_kernel(const W
       const int iy = hy0 + (x_rc[u] >> 16), ix = hx0 + (x_rc[u] & 0xffff);
       const bool ok = px < npxX && (unsigned)iy < (unsigned)k.H && (unsigned)ix < (unsigned)k.W;
       xv[u] = make_uint4(0u, 0u, 0u, 0u);
-      if (ok) { xv[u] = ldg16(xn + x_rel[u]); xok |= 1u << u; }
+      if (ok && !(k.dbg & 1)) { xv[u] = ldg16(xn + x_rel[u]); xok |= 1u << u; }
     }
   };
-  auto store_tile = [&]() {
+  auto store_tile = [&](const auto& gv, const auto& xv, unsigned xok) {
 #pragma unroll
     for (int u = 0; u < GS; ++u) {
       const int px = pg0 + u * PGS;
-      if (px < npxG) *reinterpret_cast<uint4*>(gl + px * k.pixbG + cg * 16) = gv[u];
+      if (px < npxG && !(k.dbg & 4)) *reinterpret_cast<uint4*>(gl + px * k.pixbG + cg * 16) = gv[u];
     }
 #pragma unroll
     for (int u = 0; u < XS; ++u) {
@@ -172,7 +181,7 @@ __global__ __launch_bounds__(256, (TPG == 25 ? 2 : 1)) void wgrad_kernel(const W
         for (int e = 0; e < CPU; ++e) f[e] = fmaxf(fmaf(f[e] - xsub[e], xsc[e], xsh[e]), xlo[e]);
         v = ET<T>::pack(f);
       }
-      if (px < npxX) *reinterpret_cast<uint4*>(xl + px * k.pixbX + cx * 16) = v;
+      if (px < npxX && !(k.dbg & 4)) *reinterpret_cast<uint4*>(xl + px * k.pixbX + cx * 16) = v;
     }
   };
 
@@ -182,17 +191,9 @@ __global__ __launch_bounds__(256, (TPG == 25 ? 2 : 1)) void wgrad_kernel(const W
   for (int t = 0; t < TPG; ++t)
     toff[t] = (t0 + t < k.ntaps) ? ((k.dy[t0 + t] - k.dymin) * k.HW + (k.dx[t0 + t] - k.dxmin)) * k.pixbX : 0;
 
-  int tile = blockIdx.x;
-  if (tile < k.ntiles) load_tile(tile);
-  while (tile < k.ntiles) {
-    __syncthreads();     // previous tile fully consumed
-    store_tile();
-    __syncthreads();
-    const int next = tile + gridDim.x;
-    if (next < k.ntiles) load_tile(next);      // in flight during the MFMA phase below
-    tile = next;
+  auto compute_tile = [&]() {
     // ---- MFMA: K-split: wave takes rows wave, wave+4, ...; N-split: every wave takes every row ----
-    for (int r = NSPLIT ? 0 : wave; r < k.TH; r += NSPLIT ? 1 : 4) {
+    for (int r = NSPLIT ? 0 : wave; r < ((k.dbg & 2) ? 1 : k.TH); r += NSPLIT ? 1 : 4) {
 #pragma unroll
       for (int ks = 0; ks < KSR; ++ks) {
         uint4 A[MA];
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(256, (TPG == 25 ? 2 : 1)) void wgrad_kernel(const W
         // Taps beyond ntaps (toff = 0) are computed and discarded: no branch.  The taps go in chunks of TC: all of a
         // chunk's LDS fragment reads are issued first, then its MFMAs, so a read's latency hides under the
         // previous MFMAs instead of being waited for tap by tap.
-        constexpr int TC = (TPG == 25) ? 5 : 1;   // (chunking the 9-tap kernels measured slower: their loops are short enough)
+        constexpr int TC = (TPG == 25) ? 5 : ((TPG == 9 && NSPLIT) ? UBR_WGRAD_TC9 : 1);   // taps per read-ahead chunk
 #pragma unroll
         for (int tc = 0; tc < TPG; tc += TC) {
           uint4 B[TC][NBW];
@@ -238,14 +239,64 @@ __global__ __launch_bounds__(256, (TPG == 25 ? 2 : 1)) void wgrad_kernel(const W
 #pragma unroll
             for (int b = 0; b < NBW; ++b)
 #pragma unroll
-              for (int a = 0; a < MA; ++a) acc[tc + tt][a][b] = mma_step<T>(acc[tc + tt][a][b], A[a], B[tt][b]);
+              for (int a = 0; a < MA; ++a) acc[tc + tt][a][b] = mma_step<T>(acc[tc + tt][a][b], B[tt][b], A[a]);   // D[cin = 4q+r][cout = l16]
           if constexpr (TC > 1) __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
+  };
+  const int G = gridDim.x;
+  int cur = blockIdx.x;
+#ifdef UBR_WGRAD_STAMPS
+  unsigned long long tS = 0, tL = 0, tC = 0, t_;
+#define UBR_STAMP(acc_) do { unsigned long long n_ = __builtin_amdgcn_s_memtime(); acc_ += n_ - t_; t_ = n_; } while (0)
+  const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+  t_ = t_begin;
+#else
+#define UBR_STAMP(acc_) do { } while (0)
+#endif
+  if (cur < k.ntiles) load_tile(cur, gvA, xvA, xokA);
+  if constexpr (DEEP) {
+    if (cur + G < k.ntiles) load_tile(cur + G, gvB, xvB, xokB);
+    UBR_STAMP(tL);
+    while (cur < k.ntiles) {
+      __syncthreads();     // previous tile fully consumed
+      store_tile(gvA, xvA, xokA);
+      __syncthreads();
+      UBR_STAMP(tS);
+      if (cur + 2 * G < k.ntiles) load_tile(cur + 2 * G, gvA, xvA, xokA);      // in flight during two MFMA phases
+      UBR_STAMP(tL);
+      compute_tile();
+      UBR_STAMP(tC);
+      cur += G;
+      if (cur >= k.ntiles) break;
+      __syncthreads();
+      store_tile(gvB, xvB, xokB);
+      __syncthreads();
+      UBR_STAMP(tS);
+      if (cur + 2 * G < k.ntiles) load_tile(cur + 2 * G, gvB, xvB, xokB);
+      UBR_STAMP(tL);
+      compute_tile();
+      UBR_STAMP(tC);
+      cur += G;
+    }
+  } else {
+    while (cur < k.ntiles) {
+      __syncthreads();     // previous tile fully consumed
+      store_tile(gvA, xvA, xokA);
+      __syncthreads();
+      const int next = cur + G;
+      if (next < k.ntiles) load_tile(next, gvA, xvA, xokA);      // in flight during the MFMA phase below
+      cur = next;
+      compute_tile();
+    }
   }
 
   float* slab = k.slabs + (long)blockIdx.x * k.ntaps * k.Cout_pad * k.Cin;
+  // The accumulators hold dW TRANSPOSED (rows = 4 consecutive input channels per lane, columns = output channels across the
+  // 16 lanes of a quad): the slab is [tap][cout][cin] with cin contiguous, so every lane owns 16 contiguous bytes per tile and
+  // the epilogue is one 16-byte store per accumulator instead of four scattered 4-byte ones (the slab write was ~40 % of the
+  // wide 9-tap kernel: 74 KB per workgroup behind only 16 pixel tiles of MFMA work).
   if constexpr (NSPLIT) {
     // every wave owns its cin fragments outright: write the slab straight from the accumulators
 #pragma unroll
@@ -254,12 +305,11 @@ __global__ __launch_bounds__(256, (TPG == 25 ? 2 : 1)) void wgrad_kernel(const W
 #pragma unroll
         for (int a = 0; a < MA; ++a)
 #pragma unroll
-          for (int b = 0; b < NBW; ++b)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int co = co0 + a * 16 + 4 * q + r, ci = ci0 + (nb0 + b) * 16 + l16;
-              slab[((long)(t0 + t) * k.Cout_pad + co) * k.Cin + ci] = acc[t][a][b][r];
-            }
+          for (int b = 0; b < NBW; ++b) {
+            const int co = co0 + a * 16 + l16, ci = ci0 + (nb0 + b) * 16 + 4 * q;
+            *reinterpret_cast<float4*>(&slab[((long)(t0 + t) * k.Cout_pad + co) * k.Cin + ci]) =
+                make_float4(acc[t][a][b][0], acc[t][a][b][1], acc[t][a][b][2], acc[t][a][b][3]);
+          }
       }
     }
   } else {
@@ -273,26 +323,30 @@ __global__ __launch_bounds__(256, (TPG == 25 ? 2 : 1)) void wgrad_kernel(const W
 #pragma unroll
           for (int a = 0; a < MA; ++a)
 #pragma unroll
-            for (int b = 0; b < NBW; ++b)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                float* p = red + (((t * MA + a) * NB + b) * 4 + r) * 64 + lane;
-                *p = (w == 0) ? acc[t][a][b][r] : (*p + acc[t][a][b][r]);
-              }
+            for (int b = 0; b < NBW; ++b) {
+              float4* p = reinterpret_cast<float4*>(red + (((t * MA + a) * NB + b) * 64 + lane) * 4);
+              const float4 v = make_float4(acc[t][a][b][0], acc[t][a][b][1], acc[t][a][b][2], acc[t][a][b][3]);
+              if (w == 0) *p = v;
+              else { const float4 o = *p; *p = make_float4(o.x + v.x, o.y + v.y, o.z + v.z, o.w + v.w); }
+            }
       }
     }
     __syncthreads();
     for (int s = wave; s < TPG * MA * NB; s += 4) {
       const int b = s % NB, a = (s / NB) % MA, t = s / (NB * MA);
       if (t0 + t < k.ntaps) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int co = co0 + a * 16 + 4 * q + r, ci = ci0 + b * 16 + l16;
-          slab[((long)(t0 + t) * k.Cout_pad + co) * k.Cin + ci] = red[(s * 4 + r) * 64 + lane];
-        }
+        const int co = co0 + a * 16 + l16, ci = ci0 + b * 16 + 4 * q;
+        *reinterpret_cast<float4*>(&slab[((long)(t0 + t) * k.Cout_pad + co) * k.Cin + ci]) = *reinterpret_cast<const float4*>(red + (s * 64 + lane) * 4);
       }
     }
   }
+#ifdef UBR_WGRAD_STAMPS
+  if (k.stamps != nullptr && tid == 0) {
+    const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+    unsigned long long* o = k.stamps + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8;
+    o[0] = tS; o[1] = tL; o[2] = tC; o[3] = t_end - t_; o[4] = t_end - t_begin; o[5] = t_begin;
+  }
+#endif
 }
 
 struct WPlan { int MA, NB, TPG, TH, HH, HW, pixbG, pixbX, x_off, tiles_x, tiles_y, ntiles, nsplit, gy, gz, nsplit_mode, bigx; size_t lds; };
@@ -499,6 +553,8 @@ extern "C" int ubr_wgrad(const ubr_wgrad_desc* d, void* stream) {
   UBR_CHECK((long)d->H * k.x_sy < (1L << 31) && (long)d->GH * k.g_sy < (1L << 31), "ubr_wgrad: image too large for 32-bit offsets");
   k.x_sy32 = (int)k.x_sy; k.x_sx32 = (int)k.x_sx; k.g_sy32 = (int)k.g_sy; k.g_sx32 = (int)k.g_sx;
   k.n_cot = d->Cout / (p.MA * 16);
+  { static const int dbg = [] { const char* e = getenv("UBR_WGRAD_DBG"); return e ? atoi(e) : 0; }(); k.dbg = dbg; }
+  { static const char* sp = getenv("UBR_WGRAD_STAMP_PTR"); k.stamps = sp ? (unsigned long long*)strtoull(sp, nullptr, 0) : nullptr; }
   for (int t = 0; t < d->ntaps; ++t) { k.dy[t] = d->dy[t]; k.dx[t] = d->dx[t]; }
   hipStream_t st = (hipStream_t)stream;
   switch (d->dtype) {
