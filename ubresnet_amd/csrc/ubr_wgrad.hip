@@ -22,6 +22,7 @@
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 
 struct WgK {
   const char* x; long x_sn, x_sy, x_sx;
@@ -116,18 +117,23 @@ __global__ __launch_bounds__(256, (TPG == 25 ? 2 : 1)) void wgrad_kernel(const W
   // (72 MFMAs per wave, ~0.5 us) is shorter than a round trip to HBM under load -- the wide 9-tap kernel spent more time
   // waiting for the next tile than computing.
   constexpr bool DEEP = TPG != 25;
-  uint4 gvA[GS], xvA[XS], gvB[DEEP ? GS : 1], xvB[DEEP ? XS : 1];
+  u32x4_t gvA[GS], xvA[XS], gvB[DEEP ? GS : 1], xvB[DEEP ? XS : 1];
   unsigned xokA = 0u, xokB = 0u;
 
-  // A thread's staging slots cover the same tile-relative pixels in every tile: their (row, col), bounds keys and
-  // byte offsets relative to the tile origin are computed ONCE, so the per-tile work per 16-byte item is two
-  // bounds compares and one add (no division, no 64-bit multiply).
-  int g_rc[GS], g_rel[GS];                 // (row << 16 | col), byte offset relative to the tile's first pixel
+  // A thread's staging slots cover the same tile-relative pixels in every tile, so everything about a slot that does not
+  // depend on the tile is computed ONCE: its byte offset relative to the tile origin (channel unit included; out of range
+  // for slots beyond the tile), its row / column for the image-edge tests, its LDS address.  Per tile and slot that leaves one
+  // add, one column compare and a select in front of a buffer load whose range check supplies the zero rows above and below
+  // the image (the per-image resource covers exactly the image).  With one wave per SIMD every instruction of this phase is
+  // serial issue time: the guarded-load form (two compares, a branch and 64-bit address arithmetic per slot) took 1.9 k of the
+  // 7.8 k cycles a 256-channel tile costs, 1.2 k of them MFMA (in-kernel cycle stamps, tools/microbench.py kernelonly).
+  constexpr int kOOR = (int)0x80000000;
+  int g_col[GS], g_rel[GS];
 #pragma unroll
   for (int u = 0; u < GS; ++u) {
     const int px = pg0 + u * PGS;
-    g_rc[u] = ((px >> 5) << 16) | (px & 31);
-    g_rel[u] = (px >> 5) * k.g_sy32 + (px & 31) * k.g_sx32;
+    g_col[u] = px & 31;
+    g_rel[u] = px < npxG ? (px >> 5) * k.g_sy32 + (px & 31) * k.g_sx32 + (co0 + cg * CPU) * ESZ : kOOR;
   }
   int x_rc[XS], x_rel[XS];
 #pragma unroll
@@ -135,8 +141,9 @@ __global__ __launch_bounds__(256, (TPG == 25 ? 2 : 1)) void wgrad_kernel(const W
     const int px = px0 + u * PXS_T;
     const int hy = (int)__umulhi((unsigned)px, k.hw_magic), hx = px - hy * k.HW;
     x_rc[u] = (hy << 16) | hx;
-    x_rel[u] = hy * k.x_sy32 + hx * k.x_sx32;
+    x_rel[u] = px < npxX ? hy * k.x_sy32 + hx * k.x_sx32 + (ci0 + cx * CPU) * ESZ : kOOR;
   }
+  const int g_img = k.GH * k.g_sy32, x_img = k.H * k.x_sy32;      // bytes of one image (rows beyond it read as zero)
 
   auto load_tile = [&](int tile, auto& gv, auto& xv, unsigned& xok) {
     int tt = tile;
@@ -144,44 +151,57 @@ __global__ __launch_bounds__(256, (TPG == 25 ? 2 : 1)) void wgrad_kernel(const W
     const int ty = tt % k.tiles_y;
     const int n = tt / k.tiles_y;
     const int oy0 = ty * k.TH, ox0 = tx * 32;
-    const char* gn = k.g + (long)n * k.g_sn + (long)(co0 + cg * CPU) * ESZ + ((long)oy0 * k.g_sy32 + (long)ox0 * k.g_sx32);
-    const int gry = k.GH - oy0, grx = k.GW - ox0;          // rows / cols of the gradient grid left from the tile origin
+    const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc((void*)(k.g + (long)n * k.g_sn), 0, g_img, 0x00020000);
+    const int gorg = oy0 * k.g_sy32 + ox0 * k.g_sx32;
+    const int grx = k.GW - ox0;          // columns of the gradient grid left from the tile origin
 #pragma unroll
     for (int u = 0; u < GS; ++u) {
-      const int px = pg0 + u * PGS;
-      gv[u] = make_uint4(0u, 0u, 0u, 0u);
-      if (px < npxG && (g_rc[u] >> 16) < gry && (g_rc[u] & 0xffff) < grx && !(k.dbg & 1)) gv[u] = ldg16(gn + g_rel[u]);
+      int vo = g_col[u] < grx ? g_rel[u] + gorg : -1;
+#ifdef UBR_WGRAD_STAMPS
+      if (k.dbg & 1) vo = -1;
+#endif
+      gv[u] = __builtin_amdgcn_raw_buffer_load_b128(gr, vo, 0, 0);
     }
     const int hy0 = oy0 * k.S + k.iy0 + k.dymin, hx0 = ox0 * k.S + k.ix0 + k.dxmin;
-    const char* xn = k.x + (long)n * k.x_sn + (long)(ci0 + cx * CPU) * ESZ + ((long)hy0 * k.x_sy32 + (long)hx0 * k.x_sx32);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)(k.x + (long)n * k.x_sn), 0, x_img, 0x00020000);
+    const int xorg = hy0 * k.x_sy32 + hx0 * k.x_sx32;      // negative above / left of the image: the sum wraps out of range
     xok = 0u;
 #pragma unroll
     for (int u = 0; u < XS; ++u) {
-      const int px = px0 + u * PXS_T;
-      const int iy = hy0 + (x_rc[u] >> 16), ix = hx0 + (x_rc[u] & 0xffff);
-      const bool ok = px < npxX && (unsigned)iy < (unsigned)k.H && (unsigned)ix < (unsigned)k.W;
-      xv[u] = make_uint4(0u, 0u, 0u, 0u);
-      if (ok && !(k.dbg & 1)) { xv[u] = ldg16(xn + x_rel[u]); xok |= 1u << u; }
+      const bool okx = (unsigned)(hx0 + (x_rc[u] & 0xffff)) < (unsigned)k.W;
+      int vo = okx ? x_rel[u] + xorg : -1;
+#ifdef UBR_WGRAD_STAMPS
+      if (k.dbg & 1) vo = -1;
+#endif
+      xv[u] = __builtin_amdgcn_raw_buffer_load_b128(xr, vo, 0, 0);
+      if (has_xf) xok |= (okx && x_rel[u] != kOOR && (unsigned)(hy0 + (x_rc[u] >> 16)) < (unsigned)k.H) ? (1u << u) : 0u;   // padding stays zero through the transform
     }
   };
+  // LDS side: complete slots (every thread has a pixel) and the partial one are wave-uniform tests
+  char* const gl_w = gl + pg0 * k.pixbG + cg * 16;
+  char* const xl_w = xl + px0 * k.pixbX + cx * 16;
+  const int ginc = PGS * k.pixbG, xinc = PXS_T * k.pixbX;
+  const int gfull = npxG / PGS, grem = npxG % PGS, xfull = npxX / PXS_T, xrem = npxX % PXS_T;
   auto store_tile = [&](const auto& gv, const auto& xv, unsigned xok) {
+#ifdef UBR_WGRAD_STAMPS
+    if (k.dbg & 4) return;
+#endif
 #pragma unroll
-    for (int u = 0; u < GS; ++u) {
-      const int px = pg0 + u * PGS;
-      if (px < npxG && !(k.dbg & 4)) *reinterpret_cast<uint4*>(gl + px * k.pixbG + cg * 16) = gv[u];
-    }
+    for (int u = 0; u < GS; ++u)
+      if (u < gfull || (u == gfull && pg0 < grem)) *reinterpret_cast<u32x4_t*>(gl_w + u * ginc) = gv[u];
 #pragma unroll
     for (int u = 0; u < XS; ++u) {
-      const int px = px0 + u * PXS_T;
-      uint4 v = xv[u];
-      if (has_xf && ((xok >> u) & 1u)) {
+      u32x4_t v = xv[u];
+      if (has_xf) {
         float f[CPU];
-        ET<T>::unpack(v, f);
+        ET<T>::unpack(make_uint4(v.x, v.y, v.z, v.w), f);
 #pragma unroll
         for (int e = 0; e < CPU; ++e) f[e] = fmaxf(fmaf(f[e] - xsub[e], xsc[e], xsh[e]), xlo[e]);
-        v = ET<T>::pack(f);
+        const uint4 t4 = ET<T>::pack(f);
+        const bool ok = (xok >> u) & 1u;
+        v.x = ok ? t4.x : 0u; v.y = ok ? t4.y : 0u; v.z = ok ? t4.z : 0u; v.w = ok ? t4.w : 0u;
       }
-      if (px < npxX && !(k.dbg & 4)) *reinterpret_cast<uint4*>(xl + px * k.pixbX + cx * 16) = v;
+      if (u < xfull || (u == xfull && px0 < xrem)) *reinterpret_cast<u32x4_t*>(xl_w + u * xinc) = v;
     }
   };
 
@@ -193,7 +213,12 @@ __global__ __launch_bounds__(256, (TPG == 25 ? 2 : 1)) void wgrad_kernel(const W
 
   auto compute_tile = [&]() {
     // ---- MFMA: K-split: wave takes rows wave, wave+4, ...; N-split: every wave takes every row ----
-    for (int r = NSPLIT ? 0 : wave; r < ((k.dbg & 2) ? 1 : k.TH); r += NSPLIT ? 1 : 4) {
+#ifdef UBR_WGRAD_STAMPS
+    const int nrows = (k.dbg & 2) ? 1 : k.TH;
+#else
+    const int nrows = k.TH;
+#endif
+    for (int r = NSPLIT ? 0 : wave; r < nrows; r += NSPLIT ? 1 : 4) {
 #pragma unroll
       for (int ks = 0; ks < KSR; ++ks) {
         uint4 A[MA];
