@@ -87,6 +87,29 @@ template <> struct ET<f16_t> {
   static __device__ __forceinline__ void st(void* p, long i, float v) { ((_Float16*)p)[i] = (_Float16)v; }
 };
 
+// BatchNorm + ReLU on load, `max((x - mean) * scale + shift, lo)` per channel (lo = 0 or -inf): the same IEEE operations as the
+// scalar form -- a subtraction, a fused multiply-add, a max -- issued two channels at a time (v_pk_add_f32 / v_pk_fma_f32) and
+// with v_max_f32 written out: for an operand it cannot prove canonical, fmaxf() costs a second v_max_f32 (x, x) in front of
+// the real one.  This transform is most of the VALU work of every staging phase, and VALU issue slots are what the two streams
+// of a training step compete for.
+typedef float ubr_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float ubr_vmax(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+template <int N>
+__device__ __forceinline__ void ubr_bnrelu(float* f, const float* sub, const float* sc, const float* sh, const float* lo) {
+#pragma unroll
+  for (int e = 0; e < N; e += 2) {
+    ubr_f2 a = {f[e], f[e + 1]};
+    a = a - ubr_f2{sub[e], sub[e + 1]};
+    a = __builtin_elementwise_fma(a, ubr_f2{sc[e], sc[e + 1]}, ubr_f2{sh[e], sh[e + 1]});
+    f[e] = ubr_vmax(a[0], lo[e]);
+    f[e + 1] = ubr_vmax(a[1], lo[e + 1]);
+  }
+}
+
 // One K-step (4 units across the 4 lane quads): acc[16 x 16] += A(16 x K) * B(K x 16).
 // a = this lane's unit of the A operand (row = lane&15), b = of the B operand (col = lane&15).
 // C/D map (all types): col = lane & 15, row = (lane >> 4) * 4 + reg.

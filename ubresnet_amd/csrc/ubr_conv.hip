@@ -237,8 +237,7 @@ __global__ __launch_bounds__(256, ((NT == 4 && FW <= 2 && !PIPE) ? 4 : 2)) void 
         if (has_xf) {
           float f[CPU];
           ET<T>::unpack(v, f);
-#pragma unroll
-          for (int e = 0; e < CPU; ++e) f[e] = fmaxf(fmaf(f[e] - xsub[e], xsc[e], xsh[e]), xlo[e]);
+          ubr_bnrelu<CPU>(f, xsub, xsc, xsh, xlo);
           const uint4 t4 = ET<T>::pack(f);
           const bool ok = (hok >> u) & 1u;          // padding stays zero
           v.x = ok ? t4.x : 0u; v.y = ok ? t4.y : 0u; v.z = ok ? t4.z : 0u; v.w = ok ? t4.w : 0u;
@@ -328,8 +327,7 @@ __global__ __launch_bounds__(256, ((NT == 4 && FW <= 2 && !PIPE) ? 4 : 2)) void 
           if (has_xf && ok[u]) {
             float f[CPU];
             ET<T>::unpack(v[u], f);
-#pragma unroll
-            for (int e = 0; e < CPU; ++e) f[e] = fmaxf(fmaf(f[e] - xsub[e], xsc[e], xsh[e]), xlo[e]);
+            ubr_bnrelu<CPU>(f, xsub, xsc, xsh, xlo);
             v[u] = ET<T>::pack(f);
           }
           if (i < nitems) *reinterpret_cast<uint4*>(halo + (i >> k.lgUPB) * k.pixb + c * 16) = v[u];
@@ -750,8 +748,7 @@ __global__ __launch_bounds__(256, 3) void conv_thin_kernel(const ThinK k) {
         if ((hok >> u) & 1u) {
           float f[CPU];
           ET<T>::unpack(v, f);
-#pragma unroll
-          for (int e = 0; e < CPU; ++e) f[e] = fmaxf(fmaf(f[e] - xsub[e], xsc[e], xsh[e]), xlo[e]);
+          ubr_bnrelu<CPU>(f, xsub, xsc, xsh, xlo);
           v = ET<T>::pack(f);
         }
       }
@@ -1044,8 +1041,7 @@ __global__ __launch_bounds__(256, 1) void conv_wide_kernel(const ConvK k) {
       if (has_xf && ((hok >> u) & 1u)) {
         float f[CPU];
         ET<T>::unpack(v, f);
-#pragma unroll
-        for (int e = 0; e < CPU; ++e) f[e] = fmaxf(fmaf(f[e] - xsub[e], xsc[e], xsh[e]), xlo[e]);
+        ubr_bnrelu<CPU>(f, xsub, xsc, xsh, xlo);
         v = ET<T>::pack(f);
       }
       if (i < nitems) *reinterpret_cast<uint4*>(halo + (i >> k.lgUPB) * k.pixb + c * 16) = v;

@@ -332,8 +332,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const PoolK k) {
         float v[CPU];
         ldunit<T>(k.x, ip, k.x_ps, ix.c, v);
         if (xf) {
-#pragma unroll
-          for (int e = 0; e < CPU; ++e) v[e] = fmaxf(fmaf(v[e] - sb[e], sc[e], sh[e]), lo[e]);
+          ubr_bnrelu<CPU>(v, sb, sc, sh, lo);
         }
         if (k.amax != nullptr) {
 #pragma unroll
@@ -465,8 +464,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const PoolK k) {
             float v[CPU];
             ldunit<T>(k.x, ((long)n * k.H + yy) * k.W + xx, k.x_ps, ix.c, v);
             if (xf) {
-#pragma unroll
-              for (int e = 0; e < CPU; ++e) v[e] = fmaxf(fmaf(v[e] - sb[e], sc[e], sh[e]), lo[e]);
+              ubr_bnrelu<CPU>(v, sb, sc, sh, lo);
             }
             const bool here = (yy == iy) && (xx == jx);
 #pragma unroll
@@ -531,8 +529,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_s2_kernel(const PoolK k) {
             float v[CPU];
             ldunit<T>(k.x, ((long)n * k.H + yy) * k.W + xx, k.x_ps, ix.c, v);
             if (xf) {
-#pragma unroll
-              for (int e = 0; e < CPU; ++e) v[e] = fmaxf(fmaf(v[e] - sb[e], sc[e], sh[e]), lo[e]);
+              ubr_bnrelu<CPU>(v, sb, sc, sh, lo);
             }
 #pragma unroll
             for (int e = 0; e < CPU; ++e)

@@ -145,11 +145,20 @@ __global__ __launch_bounds__(256, (TPG == 25 ? 2 : 1)) void wgrad_kernel(const W
   }
   const int g_img = k.GH * k.g_sy32, x_img = k.H * k.x_sy32;      // bytes of one image (rows beyond it read as zero)
 
-  auto load_tile = [&](int tile, auto& gv, auto& xv, unsigned& xok) {
-    int tt = tile;
-    const int tx = tt % k.tiles_x; tt /= k.tiles_x;
-    const int ty = tt % k.tiles_y;
-    const int n = tt / k.tiles_y;
+  // Successive load_tile calls walk tiles blockIdx.x, +G, +2G, ...: the (column, row, image) decomposition is carried along
+  // and advanced by the decomposition of the grid stride instead of being re-derived by three divisions per tile.
+  int nx_tx, nx_ty, nx_n, st_tx, st_ty, st_n;
+  {
+    int tt = blockIdx.x;
+    nx_tx = tt % k.tiles_x; tt /= k.tiles_x; nx_ty = tt % k.tiles_y; nx_n = tt / k.tiles_y;
+    tt = gridDim.x;
+    st_tx = tt % k.tiles_x; tt /= k.tiles_x; st_ty = tt % k.tiles_y; st_n = tt / k.tiles_y;
+  }
+  auto load_tile = [&](auto& gv, auto& xv, unsigned& xok) {
+    const int tx = nx_tx, ty = nx_ty, n = nx_n;
+    nx_tx += st_tx; nx_ty += st_ty; nx_n += st_n;
+    if (nx_tx >= k.tiles_x) { nx_tx -= k.tiles_x; nx_ty += 1; }
+    if (nx_ty >= k.tiles_y) { nx_ty -= k.tiles_y; nx_n += 1; }
     const int oy0 = ty * k.TH, ox0 = tx * 32;
     const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc((void*)(k.g + (long)n * k.g_sn), 0, g_img, 0x00020000);
     const int gorg = oy0 * k.g_sy32 + ox0 * k.g_sx32;
@@ -195,8 +204,7 @@ __global__ __launch_bounds__(256, (TPG == 25 ? 2 : 1)) void wgrad_kernel(const W
       if (has_xf) {
         float f[CPU];
         ET<T>::unpack(make_uint4(v.x, v.y, v.z, v.w), f);
-#pragma unroll
-        for (int e = 0; e < CPU; ++e) f[e] = fmaxf(fmaf(f[e] - xsub[e], xsc[e], xsh[e]), xlo[e]);
+        ubr_bnrelu<CPU>(f, xsub, xsc, xsh, xlo);
         const uint4 t4 = ET<T>::pack(f);
         const bool ok = (xok >> u) & 1u;
         v.x = ok ? t4.x : 0u; v.y = ok ? t4.y : 0u; v.z = ok ? t4.z : 0u; v.w = ok ? t4.w : 0u;
@@ -280,16 +288,16 @@ __global__ __launch_bounds__(256, (TPG == 25 ? 2 : 1)) void wgrad_kernel(const W
 #else
 #define UBR_STAMP(acc_) do { } while (0)
 #endif
-  if (cur < k.ntiles) load_tile(cur, gvA, xvA, xokA);
+  if (cur < k.ntiles) load_tile(gvA, xvA, xokA);
   if constexpr (DEEP) {
-    if (cur + G < k.ntiles) load_tile(cur + G, gvB, xvB, xokB);
+    if (cur + G < k.ntiles) load_tile(gvB, xvB, xokB);
     UBR_STAMP(tL);
     while (cur < k.ntiles) {
       __syncthreads();     // previous tile fully consumed
       store_tile(gvA, xvA, xokA);
       __syncthreads();
       UBR_STAMP(tS);
-      if (cur + 2 * G < k.ntiles) load_tile(cur + 2 * G, gvA, xvA, xokA);      // in flight during two MFMA phases
+      if (cur + 2 * G < k.ntiles) load_tile(gvA, xvA, xokA);      // in flight during two MFMA phases
       UBR_STAMP(tL);
       compute_tile();
       UBR_STAMP(tC);
@@ -299,7 +307,7 @@ __global__ __launch_bounds__(256, (TPG == 25 ? 2 : 1)) void wgrad_kernel(const W
       store_tile(gvB, xvB, xokB);
       __syncthreads();
       UBR_STAMP(tS);
-      if (cur + 2 * G < k.ntiles) load_tile(cur + 2 * G, gvB, xvB, xokB);
+      if (cur + 2 * G < k.ntiles) load_tile(gvB, xvB, xokB);
       UBR_STAMP(tL);
       compute_tile();
       UBR_STAMP(tC);
@@ -311,7 +319,7 @@ __global__ __launch_bounds__(256, (TPG == 25 ? 2 : 1)) void wgrad_kernel(const W
       store_tile(gvA, xvA, xokA);
       __syncthreads();
       const int next = cur + G;
-      if (next < k.ntiles) load_tile(next, gvA, xvA, xokA);      // in flight during the MFMA phase below
+      if (next < k.ntiles) load_tile(gvA, xvA, xokA);      // in flight during the MFMA phase below
       cur = next;
       compute_tile();
     }
