@@ -86,6 +86,28 @@ elif what.startswith("wgrad"):
         fn = lambda: ops.wgrad(x, g, taps, dW, Cin * k * k, k * k, Cout, Cin, ws, xf=xfw)
     nbytes = x.numel() * 2 + g.numel() * 2
     flops = 2.0 * N * HW * HW * Cin * Cout * k * k
+elif what.startswith(("bnred", "bnapp", "tailred", "tailapp")):
+    # BatchNorm / block-tail backward passes at a network level: bnred16 = reduce pass, 16 channels at 512x512 (32 -> 256x256 ...)
+    C = int(what.lstrip("bnredaptil"))
+    HW = 512 * 16 // C
+    f32 = lambda: torch.rand(C, device=dev) + 0.5
+    g, c, o = mk(N, HW, HW, C), mk(N, HW, HW, C), mk(N, HW, HW, C)
+    sc, sh, mu, istd, k1, k2 = f32(), f32(), f32(), f32(), f32(), f32()
+    red = torch.zeros(64 * 2 * C, dtype=torch.float64, device=dev)
+    gc, gs = torch.empty_like(c), torch.empty_like(c)
+    if what.startswith("bnred"):
+        fn = lambda: ops.bn_bwd_reduce(g, None, c, sc, sh, mu, istd, True, red)
+        nbytes = 2 * g.numel() * 2
+    elif what.startswith("bnapp"):
+        fn = lambda: ops.bn_bwd_apply(g, None, c, sc, sh, mu, istd, True, k1, k2, gc)
+        nbytes = 3 * g.numel() * 2
+    elif what.startswith("tailred"):
+        fn = lambda: ops.block_tail_bwd_reduce(g, None, o, c, sc, sh, mu, istd, None, None, None, red, None)
+        nbytes = 3 * g.numel() * 2
+    else:
+        fn = lambda: ops.block_tail_bwd_apply(g, None, o, c, sc, sh, mu, istd, k1, k2, None, None, None, None, None, None, gc, gs)
+        nbytes = 5 * g.numel() * 2
+    flops = 0.0
 else:
     raise SystemExit("unknown " + what)
 for _ in range(3):
