@@ -174,6 +174,9 @@ def test_whole_view_full_size_event(golden_dir):
     assert torch.equal(out, seg(view))
     eager = deploy.WholeViewSegmenter(m, rows, cols, planes=P, tile=(th, tw), batch=10, dtype=torch.float16, use_graph=False)
     assert torch.equal(out, eager(view)), "hipGraph replay differs from eager launches"
+    whole = deploy.WholeViewSegmenter(m, rows, cols, planes=P, tile=(th, tw), batch=30, dtype=torch.float16, use_graph=True)
+    assert torch.equal(out, whole(view)), "one replay of 30 tiles (bench.py's setting) differs from three replays of 10"
+    del whole
     m.compute_dtype = torch.float16
     with torch.no_grad():
         for i in (0, 7, 19, 29):                        # spot tiles: per-tile eager forward == the stitched keep window
