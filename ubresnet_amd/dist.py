@@ -24,9 +24,15 @@ class GradAllReducer:
 
     Gradient accumulation (several backward passes per optimizer step, or zero_grad(set_to_none=False)): the first pass
     of a step is exchanged bucket by bucket during backward; a pass that finds existing .grad tensors accumulates locally
-    and `finish()` all-reduces the accumulated .grad tensors (see autograd_fn._NetFn.backward)."""
+    and `finish()` all-reduces the accumulated .grad tensors (see autograd_fn._NetFn.backward).
 
-    def __init__(self, model, bucket_bytes: int = 16 << 20, group=None, broadcast_init: bool = True):
+    Bucket size: gradients complete head -> decoder -> encoder -> stem, and the large tensors (enc/dec level 5: 9.4 MB per
+    3x3x512x512 convolution) finish in the middle of backward, so every bucket but the last overlaps the remaining
+    backward.  The LAST bucket is the exposed one: it can only start when the stem's gradient exists.  With 8 MB buckets
+    the 256-channel encoder level (9.4 MB) leaves on its own while levels 3..1 are still running and the tail is the
+    ~3 MB of the shallow levels; with 16 MB they waited together for the end of backward (a 13 MB tail)."""
+
+    def __init__(self, model, bucket_bytes: int = 8 << 20, group=None, broadcast_init: bool = True):
         self.model = model
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
