@@ -25,7 +25,7 @@ def aff(C):
 
 
 cfgs = {"conv16": (512, 16, 16, 3), "conv32": (256, 32, 32, 3), "conv64": (128, 64, 64, 3), "conv7": (512, 16, 16, 7),
-        "conv128": (64, 128, 128, 3), "conv256": (32, 256, 256, 3), "conv512": (16, 512, 512, 3),
+        "conv1x1": (512, 16, 32, 1), "conv1x1b": (512, 32, 16, 1), "conv128": (64, 128, 128, 3), "conv256": (32, 256, 256, 3), "conv512": (16, 512, 512, 3),
         "wgrad16": (512, 16, 16, 3), "wgrad32": (256, 32, 32, 3), "wgrad64": (128, 64, 64, 3), "wgrad256": (32, 256, 256, 3)}
 if what.startswith("conv"):
     HW, Cin, Cout, k = cfgs[what]
@@ -49,7 +49,8 @@ if what.startswith("conv"):
             print("stamps (median cycles of wave 0 per workgroup, %d WGs): barriers %d, load wait %d, transform+LDS store %d, load issue %d, mfma loop %d, total before epilogue %d"
                   % (len(st), m[3], m[6], m[0], m[1], m[2], m[4]))
     atexit.register(_dump)
-    fn = lambda: ops.conv(x, wp, y, ctaps, Cout, xf=xf, stats=stats, tile_hint=hint)
+    ad = torch.zeros_like(y) if "addend" in sys.argv else None
+    fn = lambda: ops.conv(x, wp, y, ctaps, Cout, xf=xf, stats=stats, tile_hint=hint, addend=ad)
     nbytes = x.numel() * 2 + y.numel() * 2
     flops = 2.0 * N * HW * HW * Cin * Cout * k * k
 elif what.startswith("wgrad"):

@@ -93,6 +93,7 @@ template <> struct ET<f16_t> {
 // the real one.  This transform is most of the VALU work of every staging phase, and VALU issue slots are what the two streams
 // of a training step compete for.
 typedef float ubr_f2 __attribute__((ext_vector_type(2)));
+typedef unsigned ubr_u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float ubr_vmax(float a, float b) {
   float r;
   asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));

@@ -84,8 +84,6 @@ __host__ __device__ constexpr int conv_pixb(int upb) { return upb == 2 ? 32 : up
 __host__ __device__ constexpr int conv_pipe_hslots(int fw, int twf) { return ((4 * fw / twf + 2) * (twf * 16 + 2) * 4 + 255) / 256; }
 __host__ __device__ constexpr int conv_pipe_wslots(int nt) { return (36 * nt * 16 + 255) / 256; }
 
-typedef __attribute__((ext_vector_type(4))) unsigned ubr_u4;
-
 template <typename T, int FW, int NT, int TWF, bool PIPE>
 __global__ __launch_bounds__(256, ((NT == 4 && FW <= 2 && !PIPE) ? 4 : 2)) void conv_igemm_kernel(const ConvK k) {
   constexpr int TN = NT * 16;

@@ -43,6 +43,35 @@ template <typename T> __device__ __forceinline__ void stunit(void* base, long pi
   constexpr int CPU = ET<T>::CPU;
   stg16((char*)base + (pix * ps + (long)c * CPU) * (16 / CPU), ET<T>::pack(f));
 }
+// One NHWC tensor walked by a thread at its fixed channel unit: a buffer resource over the tensor and a 32-bit byte offset
+// that advances by a constant per iteration -- one add and one buffer instruction per access, where base + (pix * ps + c) * esz
+// costs a 64-bit multiply-add per tensor and iteration.  These kernels are HBM-bound on their own, but their VALU / SALU issue
+// slots are what the weight-gradient stream beside them runs on (profiles/r02_instruction_counts.txt: a quarter of all
+// VALU instructions of a train step were block-tail / BatchNorm backward).  Tensors are < 2 GiB (checked by the host side).
+template <typename T> struct UnitStream {
+  __amdgpu_buffer_rsrc_t r;
+  unsigned off, step;
+  __device__ __forceinline__ UnitStream(const void* base, long npix, long ps, const UnitIdx<T>& ix) {
+    constexpr unsigned ESZ = 16 / ET<T>::CPU;
+    r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, base != nullptr ? (int)(npix * ps * ESZ) : 0, 0x00020000);
+    off = (unsigned)ix.p * (unsigned)ps * ESZ + (unsigned)ix.c * 16u;
+    step = (unsigned)ix.pstep * (unsigned)ps * ESZ;
+  }
+  __device__ __forceinline__ void ld(float* f) const {
+    const ubr_u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+    ET<T>::unpack(make_uint4(v.x, v.y, v.z, v.w), f);
+  }
+  __device__ __forceinline__ void st(const float* f) const {
+    const uint4 v = ET<T>::pack(f);
+    __builtin_amdgcn_raw_buffer_store_b128(ubr_u4{v.x, v.y, v.z, v.w}, r, (int)off, 0, 0);
+  }
+  __device__ __forceinline__ void next() { off += step; }
+};
+template <int CPU> __device__ __forceinline__ void ldconst2(const float* a, int c, ubr_f2* f) {
+#pragma unroll
+  for (int e = 0; e < CPU; e += 2) f[e / 2] = ubr_f2{a[c * CPU + e], a[c * CPU + e + 1]};
+}
+
 template <int CPU> __device__ __forceinline__ void ldconst(const float* a, int c, float* f) {
 #pragma unroll
   for (int e = 0; e < CPU; ++e) f[e] = a[c * CPU + e];
@@ -73,22 +102,29 @@ __global__ __launch_bounds__(256) void tail_fwd_kernel(long npix, int CU, const 
                                                        const void* sc, long sc_ps, const float* mbp, const float* sb, const float* tb, void* out, long out_ps) {
   constexpr int CPU = ET<T>::CPU;
   UnitIdx<T> ix(CU);
-  float a2[CPU], b2[CPU], m2[CPU], ab[CPU], bb[CPU], mb[CPU];
-  ldconst<CPU>(s2, ix.c, a2); ldconst<CPU>(t2, ix.c, b2); ldconst<CPU>(m2p, ix.c, m2);
+  constexpr int H2 = CPU / 2;
+  ubr_f2 a2[H2], b2[H2], m2[H2], ab[H2], bb[H2], mb[H2];
+  ldconst2<CPU>(s2, ix.c, a2); ldconst2<CPU>(t2, ix.c, b2); ldconst2<CPU>(m2p, ix.c, m2);
   const bool byp = sb != nullptr;
-  if (byp) { ldconst<CPU>(sb, ix.c, ab); ldconst<CPU>(tb, ix.c, bb); ldconst<CPU>(mbp, ix.c, mb); }
+  if (byp) { ldconst2<CPU>(sb, ix.c, ab); ldconst2<CPU>(tb, ix.c, bb); ldconst2<CPU>(mbp, ix.c, mb); }
+  UnitStream<T> C2(c2, npix, c2_ps, ix), SC(sc, npix, sc_ps, ix), OUT(out, npix, out_ps, ix);
+  const float zero = 0.f;
 #pragma unroll 2
   for (long p = ix.p; p < npix; p += ix.pstep) {
     float v[CPU], s[CPU], o[CPU];
-    ldunit<T>(c2, p, c2_ps, ix.c, v);
-    ldunit<T>(sc, p, sc_ps, ix.c, s);
+    C2.ld(v); SC.ld(s);
 #pragma unroll
-    for (int e = 0; e < CPU; ++e) {
-      const float r2 = fmaxf(fmaf(v[e] - m2[e], a2[e], b2[e]), 0.f);
-      const float sh = byp ? fmaf(s[e] - mb[e], ab[e], bb[e]) : s[e];
-      o[e] = fmaxf(r2 + sh, 0.f);
+    for (int h = 0; h < H2; ++h) {
+      // relu(bn2(c2)) + shortcut (through its own BatchNorm on a bypass block), relu: same operations as the scalar form
+      const ubr_f2 bn = __builtin_elementwise_fma(ubr_f2{v[2 * h], v[2 * h + 1]} - m2[h], a2[h], b2[h]);
+      const ubr_f2 r2 = {ubr_vmax(bn[0], zero), ubr_vmax(bn[1], zero)};
+      ubr_f2 sh = {s[2 * h], s[2 * h + 1]};
+      if (byp) sh = __builtin_elementwise_fma(sh - mb[h], ab[h], bb[h]);
+      const ubr_f2 t = r2 + sh;
+      o[2 * h] = ubr_vmax(t[0], zero); o[2 * h + 1] = ubr_vmax(t[1], zero);
     }
-    stunit<T>(out, p, out_ps, ix.c, o);
+    OUT.st(o);
+    C2.next(); SC.next(); OUT.next();
   }
 }
 
@@ -108,55 +144,70 @@ struct TailB {
 template <typename T, bool APPLY>
 __global__ __launch_bounds__(256) void tail_bwd_kernel(const TailB k) {
   constexpr int CPU = ET<T>::CPU;
+  constexpr int H2 = CPU / 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   UnitIdx<T> ix(k.CU);
   const bool byp = k.cb != nullptr;
-  float s2[CPU], t2[CPU], m2[CPU], i2[CPU], mb[CPU], ib[CPU];
-  ldconst<CPU>(k.s2, ix.c, s2); ldconst<CPU>(k.t2, ix.c, t2); ldconst<CPU>(k.m2, ix.c, m2); ldconst<CPU>(k.i2, ix.c, i2);
-  if (byp) { ldconst<CPU>(k.mb, ix.c, mb); ldconst<CPU>(k.ib, ix.c, ib); }
-  float k12[CPU], k22[CPU], k1b[CPU], k2b[CPU], sb[CPU];
+  ubr_f2 s2[H2], t2[H2], m2[H2], i2[H2], mb[H2], ib[H2];
+  ldconst2<CPU>(k.s2, ix.c, s2); ldconst2<CPU>(k.t2, ix.c, t2); ldconst2<CPU>(k.m2, ix.c, m2); ldconst2<CPU>(k.i2, ix.c, i2);
+  if (byp) { ldconst2<CPU>(k.mb, ix.c, mb); ldconst2<CPU>(k.ib, ix.c, ib); }
+  ubr_f2 k12[H2], k22[H2], k1b[H2], k2b[H2], sb[H2];
   if (APPLY) {
-    ldconst<CPU>(k.k1_2, ix.c, k12); ldconst<CPU>(k.k2_2, ix.c, k22);
-    if (byp) { ldconst<CPU>(k.k1_b, ix.c, k1b); ldconst<CPU>(k.k2_b, ix.c, k2b); ldconst<CPU>(k.sb, ix.c, sb); }
+    ldconst2<CPU>(k.k1_2, ix.c, k12); ldconst2<CPU>(k.k2_2, ix.c, k22);
+    if (byp) { ldconst2<CPU>(k.k1_b, ix.c, k1b); ldconst2<CPU>(k.k2_b, ix.c, k2b); ldconst2<CPU>(k.sb, ix.c, sb); }
   }
   float acc[4][CPU];
 #pragma unroll
   for (int qn = 0; qn < 4; ++qn)
 #pragma unroll
     for (int e = 0; e < CPU; ++e) acc[qn][e] = 0.f;
+  UnitStream<T> GO(k.go, k.npix, k.go_ps, ix), GO2(k.go2, k.npix, k.go2_ps, ix), OUT(k.out, k.npix, k.out_ps, ix),
+      C2(k.c2, k.npix, k.c2_ps, ix), CB(k.cb, k.npix, k.cb_ps, ix), GC2(k.g_c2, k.npix, k.g_c2_ps, ix), GSC(k.g_sc, k.npix, k.g_sc_ps, ix);
 
 #pragma unroll 2
   for (long p = ix.p; p < k.npix; p += ix.pstep) {
     float g[CPU], o[CPU], c2[CPU], cb[CPU];
-    ldunit<T>(k.go, p, k.go_ps, ix.c, g);
+    GO.ld(g);
     if (k.go2 != nullptr) {
       float g2[CPU];
-      ldunit<T>(k.go2, p, k.go2_ps, ix.c, g2);
+      GO2.ld(g2);
 #pragma unroll
       for (int e = 0; e < CPU; ++e) g[e] += g2[e];
     }
-    ldunit<T>(k.out, p, k.out_ps, ix.c, o);
-    ldunit<T>(k.c2, p, k.c2_ps, ix.c, c2);
-    if (byp) ldunit<T>(k.cb, p, k.cb_ps, ix.c, cb);
+    OUT.ld(o);
+    C2.ld(c2);
+    if (byp) CB.ld(cb);
     float r2[CPU], rs[CPU];
 #pragma unroll
-    for (int e = 0; e < CPU; ++e) {
-      const float gz = o[e] > 0.f ? g[e] : 0.f;
-      const float gy2 = fmaf(c2[e] - m2[e], s2[e], t2[e]) > 0.f ? gz : 0.f;
-      const float xh2 = (c2[e] - m2[e]) * i2[e];
+    for (int h = 0; h < H2; ++h) {
+      // (the same operations, in the same order, as the scalar form: out > 0 gates the incoming gradient, relu(bn2) gates the
+      // branch through conv2; xh = (c - mean) * invstd; apply: s * (gy - k1 - xh * k2))
+      const ubr_f2 d2 = ubr_f2{c2[2 * h], c2[2 * h + 1]} - m2[h];
+      const ubr_f2 bn = __builtin_elementwise_fma(d2, s2[h], t2[h]);
+      const ubr_f2 xh2 = d2 * i2[h];
+      const ubr_f2 gz = {o[2 * h] > 0.f ? g[2 * h] : 0.f, o[2 * h + 1] > 0.f ? g[2 * h + 1] : 0.f};
+      const ubr_f2 gy2 = {bn[0] > 0.f ? gz[0] : 0.f, bn[1] > 0.f ? gz[1] : 0.f};
+      ubr_f2 xhb = {0.f, 0.f};
+      if (byp) xhb = (ubr_f2{cb[2 * h], cb[2 * h + 1]} - mb[h]) * ib[h];
       if (APPLY) {
-        r2[e] = s2[e] * (gy2 - k12[e] - xh2 * k22[e]);
-        if (byp) { const float xhb = (cb[e] - mb[e]) * ib[e]; rs[e] = sb[e] * (gz - k1b[e] - xhb * k2b[e]); }
-        else rs[e] = gz;
+        const ubr_f2 a = s2[h] * (gy2 - k12[h] - xh2 * k22[h]);
+        r2[2 * h] = a[0]; r2[2 * h + 1] = a[1];
+        ubr_f2 b = gz;
+        if (byp) b = sb[h] * (gz - k1b[h] - xhb * k2b[h]);
+        rs[2 * h] = b[0]; rs[2 * h + 1] = b[1];
       } else {
-        acc[0][e] += gy2; acc[1][e] += gy2 * xh2;
-        if (byp) { const float xhb = (cb[e] - mb[e]) * ib[e]; acc[2][e] += gz; acc[3][e] += gz * xhb; }
+        const ubr_f2 gx = gy2 * xh2;
+        acc[0][2 * h] += gy2[0]; acc[0][2 * h + 1] += gy2[1];
+        acc[1][2 * h] += gx[0]; acc[1][2 * h + 1] += gx[1];
+        if (byp) {
+          const ubr_f2 gb = gz * xhb;
+          acc[2][2 * h] += gz[0]; acc[2][2 * h + 1] += gz[1];
+          acc[3][2 * h] += gb[0]; acc[3][2 * h + 1] += gb[1];
+        }
       }
     }
-    if (APPLY) {
-      stunit<T>(k.g_c2, p, k.g_c2_ps, ix.c, r2);
-      stunit<T>(k.g_sc, p, k.g_sc_ps, ix.c, rs);
-    }
+    if (APPLY) { GC2.st(r2); GSC.st(rs); GC2.next(); GSC.next(); }
+    GO.next(); GO2.next(); OUT.next(); C2.next(); CB.next();
   }
   if (!APPLY) {
     const size_t so = (size_t)(blockIdx.x % UBR_STAT_SLOTS) * 2 * k.C;
@@ -177,33 +228,44 @@ struct BnB {
 template <typename T, bool APPLY>
 __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnB k) {
   constexpr int CPU = ET<T>::CPU;
+  constexpr int H2 = CPU / 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   UnitIdx<T> ix(k.CU);
-  float sc[CPU], sh[CPU], mu[CPU], is[CPU], k1[CPU], k2[CPU];
-  ldconst<CPU>(k.scale, ix.c, sc); ldconst<CPU>(k.shift, ix.c, sh); ldconst<CPU>(k.mean, ix.c, mu); ldconst<CPU>(k.invstd, ix.c, is);
-  if (APPLY) { ldconst<CPU>(k.k1, ix.c, k1); ldconst<CPU>(k.k2, ix.c, k2); }
+  ubr_f2 sc[H2], sh[H2], mu[H2], is[H2], k1[H2], k2[H2];
+  ldconst2<CPU>(k.scale, ix.c, sc); ldconst2<CPU>(k.shift, ix.c, sh); ldconst2<CPU>(k.mean, ix.c, mu); ldconst2<CPU>(k.invstd, ix.c, is);
+  if (APPLY) { ldconst2<CPU>(k.k1, ix.c, k1); ldconst2<CPU>(k.k2, ix.c, k2); }
   float acc[2][CPU];
 #pragma unroll
   for (int e = 0; e < CPU; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
+  UnitStream<T> GA(k.ga, k.npix, k.ga_ps, ix), GA2(k.ga2, k.npix, k.ga2_ps, ix), CC(k.c, k.npix, k.c_ps, ix), GC(k.gc, k.npix, k.gc_ps, ix);
 #pragma unroll 2
   for (long p = ix.p; p < k.npix; p += ix.pstep) {
     float g[CPU], c[CPU], r[CPU];
-    ldunit<T>(k.ga, p, k.ga_ps, ix.c, g);
+    GA.ld(g);
     if (k.ga2 != nullptr) {
       float g2[CPU];
-      ldunit<T>(k.ga2, p, k.ga2_ps, ix.c, g2);
+      GA2.ld(g2);
 #pragma unroll
       for (int e = 0; e < CPU; ++e) g[e] += g2[e];
     }
-    ldunit<T>(k.c, p, k.c_ps, ix.c, c);
+    CC.ld(c);
 #pragma unroll
-    for (int e = 0; e < CPU; ++e) {
-      const float gy = (!k.relu || fmaf(c[e] - mu[e], sc[e], sh[e]) > 0.f) ? g[e] : 0.f;
-      const float xh = (c[e] - mu[e]) * is[e];
-      if (APPLY) r[e] = sc[e] * (gy - k1[e] - xh * k2[e]);
-      else { acc[0][e] += gy; acc[1][e] += gy * xh; }
+    for (int h = 0; h < H2; ++h) {
+      const ubr_f2 d = ubr_f2{c[2 * h], c[2 * h + 1]} - mu[h];
+      const ubr_f2 bn = __builtin_elementwise_fma(d, sc[h], sh[h]);
+      const ubr_f2 xh = d * is[h];
+      const ubr_f2 gy = {(!k.relu || bn[0] > 0.f) ? g[2 * h] : 0.f, (!k.relu || bn[1] > 0.f) ? g[2 * h + 1] : 0.f};
+      if (APPLY) {
+        const ubr_f2 a = sc[h] * (gy - k1[h] - xh * k2[h]);
+        r[2 * h] = a[0]; r[2 * h + 1] = a[1];
+      } else {
+        const ubr_f2 gx = gy * xh;
+        acc[0][2 * h] += gy[0]; acc[0][2 * h + 1] += gy[1];
+        acc[1][2 * h] += gx[0]; acc[1][2 * h + 1] += gx[1];
+      }
     }
-    if (APPLY) stunit<T>(k.gc, p, k.gc_ps, ix.c, r);
+    if (APPLY) { GC.st(r); GC.next(); }
+    GA.next(); GA2.next(); CC.next();
   }
   if (!APPLY) {
     const size_t so = (size_t)(blockIdx.x % UBR_STAT_SLOTS) * 2 * k.C;
@@ -573,6 +635,7 @@ static int check_nhwc(const char* who, int dtype, int64_t npix, int C, const voi
   const int esz = ubr_esize(dtype);
   UBR_CHECK(npix > 0 && C > 0 && C % ubr_cpu(dtype) == 0, "%s: bad extent npix=%ld C=%d", who, (long)npix, C);
   UBR_CHECK(p != nullptr && ubr_aligned16(p) && ps >= C && (ps * esz) % 16 == 0, "%s: tensor must be non-null, 16-byte aligned, pixel stride %ld >= C and 16-byte multiple", who, (long)ps);
+  UBR_CHECK(npix * ps * esz < (int64_t)1 << 31, "%s: tensor of %ld pixels x %ld elements exceeds 2 GiB (32-bit buffer offsets)", who, (long)npix, (long)ps);
   return UBR_OK;
 }
 #define UBR_TRY(x) do { int rc__ = (x); if (rc__ != UBR_OK) return rc__; } while (0)
