@@ -558,8 +558,15 @@ struct ThinK {
 // d == 1 has no 32-bit magic and is encoded as 0
 __device__ __forceinline__ unsigned udiv_magic(unsigned n, unsigned magic) { return magic == 0u ? n : __umulhi(n, magic); }
 
-template <typename T, int FW, int NT, int TWF, int UPB, bool XF, bool LSM>
-__global__ __launch_bounds__(256, 3) void conv_thin_kernel(const ThinK k) {
+// ROW7 (7x7 layers over 16 channels, 16x32-pixel tile, FW = 8): a wave owns FOUR output rows of two 16-pixel fragments and
+// walks the 4 + 6 input rows once per horizontal tap pair.  The halo fragment of input row r is the operand of output row
+// r - dy for every vertical tap dy, so one LDS fragment read feeds up to four MFMAs and the seven weight fragments of a
+// tap-pair column stay in registers: 27 fragment reads per 56 MFMAs instead of 70.  (Cout = 16 gives no reuse across
+// cout tiles: in the generic tap loop every MFMA needs a fresh 1 KB fragment and the 7x7 layers were LDS-read bound,
+// 151 us alone, ~190 us beside the weight-gradient stream.)  The horizontal taps are padded from 7 to 8 so that a K-step's two
+// taps share a row (56 virtual taps, the host supplies their table; the pad tap has zero weights): +12 % MFMAs.
+template <typename T, int FW, int NT, int TWF, int UPB, bool XF, bool LSM, bool ROW7 = false>
+__global__ __launch_bounds__(256, (ROW7 ? 2 : 3)) void conv_thin_kernel(const ThinK k) {
   constexpr int TN = NT * 16;
   constexpr int TH = 4 * FW / TWF;
   constexpr int TW = TWF * 16;
@@ -567,11 +574,12 @@ __global__ __launch_bounds__(256, 3) void conv_thin_kernel(const ThinK k) {
   constexpr int ESZ = 16 / CPU;
   constexpr int LG = UPB == 4 ? 2 : (UPB == 2 ? 1 : 0);
   constexpr int PIXB = conv_pixb(UPB);        // LDS bytes per halo pixel (conflict-free fragment reads: see conv_pixb)
-  constexpr int HS = UPB == 4 ? 6 : 5;        // halo register slots per thread (host: nitems <= 256*HS)
+  constexpr int HS = ROW7 ? 7 : (UPB == 4 ? 6 : 5);        // halo register slots per thread (host: nitems <= 256*HS)
   constexpr int PPS = 256 / UPB;              // halo pixels covered by one slot of the whole workgroup
   constexpr int WB = 4;                       // weight items per thread and batch
-  constexpr int FH = 4;                       // pixel fragments per accumulator group
+  constexpr int FH = ROW7 ? 8 : 4;            // pixel fragments per accumulator group
   static_assert(TWF == 2 && FW % FH == 0, "tile shape");
+  static_assert(!ROW7 || (FW == 8 && NT == 1 && UPB == 2), "ROW7 is the 16x32-pixel, 16-cout, 16-cin tile");
   constexpr bool WIDE = ESZ == 2;             // 16-bit outputs: one 16-byte store per lane and fragment pair
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -664,7 +672,7 @@ __global__ __launch_bounds__(256, 3) void conv_thin_kernel(const ThinK k) {
     if (u < k.nunits) {
       const int tap = u >> LG, cc = u & (UPB - 1);
       off = ((k.dy[tap] - k.dymin) * k.HW + (k.dx[tap] - k.dxmin)) * PIXB + cc * 16;
-      v = ((int)k.wt[tap] * k.CU + cc) * k.Cout_pad;
+      v = k.wt[tap] == 255 ? -1 : ((int)k.wt[tap] * k.CU + cc) * k.Cout_pad;       // 255: padding tap (zero weights)
     }
     tbl[u] = off;
     wsrc[u] = v;
@@ -784,6 +792,30 @@ __global__ __launch_bounds__(256, 3) void conv_thin_kernel(const ThinK k) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
       const char* hb = halo + fb0 + (g0 / TWF) * rowb;
+      if constexpr (ROW7) {
+        constexpr int ROWB = (TW + 6) * PIXB;          // halo row pitch (host: HW == TW + 6)
+#pragma unroll 1
+        for (int pp = 0; pp < 4; ++pp) {               // horizontal tap pairs (dx = 2pp, 2pp + 1; the last one holds the pad tap)
+          const char* pb = hb + tbl[4 * pp + q];
+          const char* pw = wl + ((4 * pp + q) * TN + l16) * 16;
+          uint4 w7[7];
+#pragma unroll
+          for (int dy = 0; dy < 7; ++dy) w7[dy] = *reinterpret_cast<const uint4*>(pw + dy * (16 * TN * 16));   // step dy*4 + pp
+#pragma unroll
+          for (int ir = 0; ir < 10; ++ir) {            // input rows of the four output rows
+            const uint4 b0 = *reinterpret_cast<const uint4*>(pb + ir * ROWB);
+            const uint4 b1 = *reinterpret_cast<const uint4*>(pb + ir * ROWB + 16 * PIXB);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int dy = ir - r;
+              if (dy >= 0 && dy <= 6) {
+                acc[2 * r][0] = mma_step<T>(acc[2 * r][0], w7[dy], b0);
+                acc[2 * r + 1][0] = mma_step<T>(acc[2 * r + 1][0], w7[dy], b1);
+              }
+            }
+          }
+        }
+      } else {
       int off_n = tbl[q];
       uint4 wf_n[NT];
 #pragma unroll
@@ -809,6 +841,7 @@ __global__ __launch_bounds__(256, 3) void conv_thin_kernel(const ThinK k) {
 #pragma unroll
           for (int j = 0; j < NT; ++j) acc[i][j] = mma_step<T>(acc[i][j], wf[j], a[i]);
       }
+      }   // !ROW7
 
       // ---- epilogue of this fragment group ----
 #pragma unroll
@@ -1197,9 +1230,9 @@ int launch_one(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
   return UBR_OK;
 }
 
-template <typename T, int FW, int NT, int TWF, int UPB, bool XF, bool LSM = false>
+template <typename T, int FW, int NT, int TWF, int UPB, bool XF, bool LSM = false, bool ROW7 = false>
 int launch_thin(const ThinK& k, dim3 grid, size_t lds, hipStream_t st) {
-  auto fn = conv_thin_kernel<T, FW, NT, TWF, UPB, XF, LSM>;
+  auto fn = conv_thin_kernel<T, FW, NT, TWF, UPB, XF, LSM, ROW7>;
   if (lds > 64 * 1024) {
     static thread_local size_t maxset = 0;
     if (lds > maxset) {
@@ -1223,7 +1256,21 @@ int try_thin(const ConvK& c, dim3 grid, hipStream_t st, int* rc) {
   static const bool thin_on = [] { const char* e = getenv("UBR_CONV_THIN"); return !e || atoi(e) != 0; }();
   const int esz = 16 / ET<T>::CPU;
   if (!thin_on || c.nblk != 1 || c.S != 1 || (c.UPB != 2 && c.UPB != 4)) return 0;
-  const int HSn = c.UPB == 4 ? 6 : 5;
+  // ROW7: the full 7x7 tap set over 16 input channels on the 16x32-pixel tile (see conv_thin_kernel)
+  int map7[7][7];
+  bool row7 = false;
+  if constexpr (FW == 8 && NT == 1 && sizeof(T) == 2) {
+    static const bool row7_on = [] { const char* e = getenv("UBR_CONV_ROW7"); return !e || atoi(e) != 0; }();
+    row7 = row7_on && c.ntaps == 49 && c.UPB == 2 && c.dymin == -3 && c.dxmin == -3 && c.HW == TW + 6 && c.HH == TH + 6;
+    if (row7) {
+      for (int a = 0; a < 7; ++a) for (int b = 0; b < 7; ++b) map7[a][b] = -1;
+      for (int t = 0; t < 49 && row7; ++t) {
+        const int a = c.dy[t] + 3, b = c.dx[t] + 3;
+        if (a < 0 || a > 6 || b < 0 || b > 6 || map7[a][b] >= 0 || c.wt[t] == 255) row7 = false; else map7[a][b] = c.wt[t];
+      }
+    }
+  }
+  const int HSn = row7 ? 7 : (c.UPB == 4 ? 6 : 5);
   if (c.HH * (int)c.rw > 256 * HSn) return 0;
   if (c.OH % TH || c.OW % TW) return 0;
   if (c.epilogue == 0 && esz == 2 && !c.wide_store) return 0;
@@ -1246,10 +1293,19 @@ int try_thin(const ConvK& c, dim3 grid, hipStream_t st, int* rc) {
   k.Cout = c.Cout; k.Cout_pad = c.Cout_pad; k.CU = c.CU; k.OH = c.OH; k.OW = c.OW;
   k.act = c.act; k.epilogue = c.epilogue; k.wlinear = c.wlinear; k.dbg = c.dbg;
   for (int t = 0; t < c.ntaps; ++t) { k.dy[t] = c.dy[t]; k.dx[t] = c.dx[t]; k.wt[t] = c.wt[t]; }
+  if (row7) {
+    // 56 virtual taps, row-major with the horizontal taps padded to 8: K-step dy*4 + p holds taps (dy, 2p) and (dy, 2p+1)
+    for (int a = 0; a < 7; ++a)
+      for (int b = 0; b < 8; ++b) {
+        const int t = a * 8 + b;
+        k.dy[t] = (int8_t)(a - 3); k.dx[t] = (int8_t)((b < 7 ? b : 6) - 3); k.wt[t] = (uint8_t)(b < 7 ? map7[a][b] : 255);
+      }
+    k.nunits = 56 * 2; k.steps = 28; k.wlinear = 0;
+  }
   // LDS: tap-offset + weight-source tables | weight slab | halo (HS slots of the whole workgroup) | statistics scratch
   const int pixb = conv_pixb(c.UPB);
-  size_t off = ((size_t)2 * 16 * c.steps + 15) & ~(size_t)15;
-  k.wl_off = (int)off; off += (size_t)4 * c.steps * TN * 16;
+  size_t off = ((size_t)2 * 16 * k.steps + 15) & ~(size_t)15;
+  k.wl_off = (int)off; off += (size_t)4 * k.steps * TN * 16;
   k.halo_off = (int)off; off += (size_t)HSn * (256 / c.UPB) * pixb;
   k.red_off = (int)off; off += (size_t)4 * TN * 2 * sizeof(float) + (size_t)4 * 4 * 8 * sizeof(float);   // + BatchNorm-on-load constants
   const size_t lds = off;
@@ -1257,7 +1313,7 @@ int try_thin(const ConvK& c, dim3 grid, hipStream_t st, int* rc) {
   // persistent grid: the workgroups that fit the chip at once (register- or LDS-limited), each walking tiles with a stride of the grid
   static const int wg_per_cu = [] { const char* e = getenv("UBR_CONV_THIN_WGS"); return e ? atoi(e) : 0; }();
   int per_cu = (int)((150 * 1024) / lds);
-  const int reg_cap = NT == 1 ? 4 : 3;          // <= 128 VGPRs for the 16-cout tiles, <= 168 for the 32-cout ones
+  const int reg_cap = row7 ? 2 : (NT == 1 ? 4 : 3);          // <= 128 VGPRs for the 16-cout tiles, <= 168 for the 32-cout ones, <= 256 for ROW7
   if (per_cu > reg_cap) per_cu = reg_cap;
   if (wg_per_cu > 0) per_cu = wg_per_cu;
   if (per_cu < 1) per_cu = 1;
@@ -1268,6 +1324,15 @@ int try_thin(const ConvK& c, dim3 grid, hipStream_t st, int* rc) {
   const bool xf = c.in_scale != nullptr;
   snprintf(g_last_conv_name, sizeof(g_last_conv_name), "conv_thin_kernel<%s, %d, %d, %d, %d, %s, %s>", sizeof(T) == 4 ? "float" : (std::is_same<T, bf16_t>::value ? "bf16_t" : "f16_t"),
            FW, NT, TWF, c.UPB, xf ? "true" : "false", c.epilogue == 1 ? "true" : "false");
+  if constexpr (FW == 8 && NT == 1 && sizeof(T) == 2) {
+    if (row7) {
+      snprintf(g_last_conv_name, sizeof(g_last_conv_name), "conv_thin_kernel<%s, 8, 1, 2, 2, %s, %s, true>", std::is_same<T, bf16_t>::value ? "bf16_t" : "f16_t",
+               xf ? "true" : "false", c.epilogue == 1 ? "true" : "false");
+      if (c.epilogue == 1) *rc = xf ? launch_thin<T, 8, 1, 2, 2, true, true, true>(k, g, lds, st) : launch_thin<T, 8, 1, 2, 2, false, true, true>(k, g, lds, st);
+      else *rc = xf ? launch_thin<T, 8, 1, 2, 2, true, false, true>(k, g, lds, st) : launch_thin<T, 8, 1, 2, 2, false, false, true>(k, g, lds, st);
+      return 1;
+    }
+  }
   if (c.epilogue == 1) {
     // conv11 + LogSoftmax (models/ub_uresnet.py:64,143): 7x7 over 16 channels, the 8x32-pixel tile
     if constexpr (FW == 4 && NT == 1) {
@@ -1432,9 +1497,12 @@ static bool thin_eligible(const ubr_conv_desc* d, int cfg, const Plan& p, bool w
   const int cpu = ubr_cpu(d->dtype), esz = ubr_esize(d->dtype);
   const int CU = d->Cin / cpu, TH = 4 * c.FW / c.TWF, TW = c.TWF * 16;
   if (p.UPB != CU || d->S != 1 || (p.UPB != 2 && p.UPB != 4)) return false;
-  if ((long)p.HH * p.HW * p.UPB > 256L * (p.UPB == 4 ? 6 : 5)) return false;
   if (d->OH % TH || d->OW % TW) return false;
-  if (d->epilogue == 1) return cfg == 1 && p.UPB == 2;
+  // the row-stationary 7x7 form (ROW7) of the 16x32-pixel tile: try_thin re-checks the tap set
+  static const bool row7_on = [] { const char* e = getenv("UBR_CONV_ROW7"); return !e || atoi(e) != 0; }();
+  const bool row7 = row7_on && cfg == 0 && esz == 2 && d->ntaps == 49 && p.UPB == 2 && p.HW == TW + 6 && p.HH == TH + 6;
+  if ((long)p.HH * p.HW * p.UPB > 256L * (row7 ? 7 : (p.UPB == 4 ? 6 : 5))) return false;
+  if (d->epilogue == 1) return (cfg == 1 || row7) && p.UPB == 2;
   if (esz == 2 && !wide_ok) return false;
   return d->Cout % 4 == 0;
 }
