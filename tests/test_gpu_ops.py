@@ -88,6 +88,10 @@ CONV_CASES = [
     (1, 96, 128, 16, 16, 3, 1, 1, False, False, True, True, 0),
     (1, 48, 64, 32, 32, 3, 1, 1, True, False, True, False, 0),
     (2, 64, 96, 16, 16, 7, 1, 1, False, True, False, False, 0),
+    # 7x7 over 16 channels: tiles of 16x32 take the row-stationary thin kernel (ROW7) in 16-bit types; hint 2 = the generic tap loop
+    (1, 32, 64, 16, 16, 7, 1, 1, True, True, True, True, 0),
+    (1, 32, 64, 16, 16, 7, 1, 1, True, True, True, True, 2),
+    (2, 16, 32, 16, 12, 7, 1, 1, False, False, True, False, 0),
     # conv_wide_kernel tiles (hint 101..106): 128- and 64-cout workgroup tiles, waves laid out WP x WN
     (1, 16, 32, 64, 128, 3, 1, 1, True, False, True, False, 101),
     (1, 8, 32, 128, 128, 3, 1, 1, False, True, True, True, 102),
@@ -522,23 +526,26 @@ def test_out_of_range_labels_raise():
 
 @pytest.mark.parametrize("dt", DTS + [torch.float16])
 @pytest.mark.parametrize("act", [1, 2, 3])
-def test_conv_inference_epilogue(dt, act):
+@pytest.mark.parametrize("ksz", [3, 7])
+def test_conv_inference_epilogue(dt, act, ksz):
     """ubr_conv_desc.act: out = relu?( relu?(conv + bias) + addend ) -- the BasicBlock tail of the inference schedule
-    (models/common_layers.py:47-56 with eval-mode BatchNorm folded into weights and bias)"""
-    N, H, W, Cin, Cout = 2, 16, 32, 32, 32
+    (models/common_layers.py:47-56 with eval-mode BatchNorm folded into weights and bias); 7x7 = conv10 of the head
+    (models/ub_uresnet.py:60), which runs the row-stationary thin kernel in fp16 / bf16"""
+    N, H, W, Cin, Cout = (2, 16, 32, 32, 32) if ksz == 3 else (2, 32, 32, 16, 16)
+    k2 = ksz * ksz
     x = rnd(dt, gen(N, Cin, H, W, seed=1))
-    w = gen(Cout, Cin, 3, 3, seed=2, scale=(2.0 / (9 * Cin)) ** 0.5)
+    w = gen(Cout, Cin, ksz, ksz, seed=2, scale=(2.0 / (k2 * Cin)) ** 0.5)
     b = gen(Cout, seed=3) * 0.5
     ad = rnd(dt, gen(N, Cout, H, W, seed=6))
-    ref = F.conv2d(x, rnd(dt, w), b, 1, 1)
+    ref = F.conv2d(x, rnd(dt, w), b, 1, ksz // 2)
     if act & 1:
         ref = F.relu(ref)
     ref = ref + ad
     if act & 2:
         ref = F.relu(ref)
     y = torch.empty((N, H, W, Cout), dtype=dt, device=DEV)
-    wp = ops.pack_weights(w.to(DEV), dt, Cout, Cin, Cin * 9, 9, 9)
-    ops.conv(nhwc(x, dt), wp, y, ops.conv_taps(3, 1, 1), Cout, bias=b.to(DEV), addend=nhwc(ad, dt), act=act)
+    wp = ops.pack_weights(w.to(DEV), dt, Cout, Cin, Cin * k2, k2, k2)
+    ops.conv(nhwc(x, dt), wp, y, ops.conv_taps(ksz, 1, ksz // 2), Cout, bias=b.to(DEV), addend=nhwc(ad, dt), act=act)
     torch.cuda.synchronize()
     close(nchw(y), ref, tol(dt), "conv act=%d" % act)
 
