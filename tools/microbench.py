@@ -46,8 +46,8 @@ if what.startswith("conv"):
         if len(st):
             m = st.float().median(0).values
             print("   prologue %d, main loop %d, epilogue %d cycles (medians)" % ((st[:, 5] - st[:, 7]).float().median(), (st[:, 8] - st[:, 5]).float().median(), (st[:, 9] - st[:, 8]).float().median()))
-            print("stamps (median cycles of wave 0 per workgroup, %d WGs): barriers %d, load wait %d, transform+LDS store %d, load issue %d, mfma loop %d, total before epilogue %d"
-                  % (len(st), m[3], m[6], m[0], m[1], m[2], m[4]))
+            print("stamps (median cycles of wave 0 per workgroup, %d WGs): barriers %d, load wait %d, transform+LDS store %d, load issue %d, mfma loop %d, thin-kernel epilogue %d, main loop total %d"
+                  % (len(st), m[3], m[6], m[0], m[1], m[2], m[10], m[4]))
     atexit.register(_dump)
     ad = torch.zeros_like(y) if "addend" in sys.argv else None
     fn = lambda: ops.conv(x, wp, y, ctaps, Cout, xf=xf, stats=stats, tile_hint=hint, addend=ad)

@@ -552,6 +552,7 @@ struct ThinK {
   int wl_off, halo_off, red_off;
   int8_t dy[UBR_MAX_TAPS], dx[UBR_MAX_TAPS];
   uint8_t wt[UBR_MAX_TAPS];
+  unsigned long long* stamps;                    // diagnostic build (-DUBR_CONV_STAMPS)
 };
 
 // exact unsigned division of small operands by a runtime divisor: magic = ceil(2^32 / d) for d >= 2 (valid while n * d < 2^32);
@@ -737,7 +738,18 @@ __global__ __launch_bounds__(256, (ROW7 ? 2 : 3)) void conv_thin_kernel(const Th
 #pragma unroll
     for (int r = 0; r < 4; ++r) { s1[j][r] = 0.f; s2[j][r] = 0.f; }
 
+#ifdef UBR_CONV_STAMPS
+  unsigned long long tS = 0, tL = 0, tC = 0, tE = 0, tB = 0, tW = 0, t_ = __builtin_amdgcn_s_memtime();
+  const unsigned long long t_begin = t_;
+#define UBR_TSTAMP(acc_) do { unsigned long long n_ = __builtin_amdgcn_s_memtime(); acc_ += n_ - t_; t_ = n_; } while (0)
+#else
+#define UBR_TSTAMP(acc_) do { } while (0)
+#endif
   while (tile < ntiles) {
+#ifdef UBR_CONV_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    UBR_TSTAMP(tW);
+#endif
     // ---- halo of this tile: transform, write to LDS (slots beyond the halo hold zeros and land in the slack of the region) ----
     float xsub[XF ? CPU : 1], xsc[XF ? CPU : 1], xsh[XF ? CPU : 1], xlo[XF ? CPU : 1];
     if constexpr (XF) {
@@ -760,7 +772,9 @@ __global__ __launch_bounds__(256, (ROW7 ? 2 : 3)) void conv_thin_kernel(const Th
       }
       *reinterpret_cast<uint4*>(halo_w + u * (PPS * PIXB)) = v;
     }
+    UBR_TSTAMP(tS);
     __syncthreads();
+    UBR_TSTAMP(tB);
     const unsigned t = (unsigned)__builtin_amdgcn_readfirstlane(tile);
     const unsigned rr = udiv_magic(t, k.tx_magic), tx = t - rr * (unsigned)k.tiles_x;
     const unsigned n = udiv_magic(rr, k.ty_magic), ty = rr - n * (unsigned)k.tiles_y;
@@ -770,6 +784,7 @@ __global__ __launch_bounds__(256, (ROW7 ? 2 : 3)) void conv_thin_kernel(const Th
     __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)(k.y + (long)n * k.y_sn), 0, (int)k.y_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc((void*)(k.ad != nullptr ? k.ad + (long)n * k.a_sn : k.x), 0, k.ad != nullptr ? (int)k.a_bytes : 0, 0x00020000);
     const int ybase = oy0 * k.y_sy + ox0 * k.y_sx, abase = oy0 * k.a_sy + ox0 * k.a_sx;
+    UBR_TSTAMP(tL);
 
 #pragma unroll 1
     for (int g0 = 0; g0 < FW; g0 += FH) {
@@ -842,6 +857,7 @@ __global__ __launch_bounds__(256, (ROW7 ? 2 : 3)) void conv_thin_kernel(const Th
           for (int j = 0; j < NT; ++j) acc[i][j] = mma_step<T>(acc[i][j], wf[j], a[i]);
       }
       }   // !ROW7
+      UBR_TSTAMP(tC);
 
       // ---- epilogue of this fragment group ----
 #pragma unroll
@@ -920,10 +936,18 @@ __global__ __launch_bounds__(256, (ROW7 ? 2 : 3)) void conv_thin_kernel(const Th
           }
         }
       }
+      UBR_TSTAMP(tE);
     }   // fragment groups
     tile = next;
     if (tile < ntiles) __syncthreads();        // every wave is done with this tile's halo image before it is overwritten
+    UBR_TSTAMP(tB);
   }
+#ifdef UBR_CONV_STAMPS
+  if (k.stamps != nullptr && tid == 0) {
+    unsigned long long* o = k.stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16;
+    o[0] = tS; o[1] = tL; o[2] = tC; o[3] = tB; o[6] = tW; o[10] = tE; o[4] = t_ - t_begin; o[5] = t_begin; o[7] = t_begin; o[8] = t_; o[9] = t_;
+  }
+#endif
 
   if (k.stats != nullptr) {
     // (fp32 partial sums span all tiles of the workgroup: <= 16 tiles x 128 pixels per lane here, then fp64)
@@ -1291,7 +1315,7 @@ int try_thin(const ConvK& c, dim3 grid, hipStream_t st, int* rc) {
   k.tx_magic = magic_u32((unsigned)c.tiles_x); k.ty_magic = magic_u32((unsigned)c.tiles_y);
   k.steps = c.steps; k.nunits = c.nunits; k.hy_org = c.iy0 + c.dymin; k.hx_org = c.ix0 + c.dxmin; k.dymin = c.dymin; k.dxmin = c.dxmin;
   k.Cout = c.Cout; k.Cout_pad = c.Cout_pad; k.CU = c.CU; k.OH = c.OH; k.OW = c.OW;
-  k.act = c.act; k.epilogue = c.epilogue; k.wlinear = c.wlinear; k.dbg = c.dbg;
+  k.act = c.act; k.epilogue = c.epilogue; k.wlinear = c.wlinear; k.dbg = c.dbg; k.stamps = c.stamps;
   for (int t = 0; t < c.ntaps; ++t) { k.dy[t] = c.dy[t]; k.dx[t] = c.dx[t]; k.wt[t] = c.wt[t]; }
   if (row7) {
     // 56 virtual taps, row-major with the horizontal taps padded to 8: K-step dy*4 + p holds taps (dy, 2p) and (dy, 2p+1)
