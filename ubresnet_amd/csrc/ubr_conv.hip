@@ -112,6 +112,42 @@ __global__ __launch_bounds__(256, ((NT == 4 && FW <= 2 && !PIPE) ? 4 : 2)) void 
   const int oy0 = ty * TH, ox0 = tx * TW;
   const int hy0 = oy0 * k.S + k.iy0 + k.dymin, hx0 = ox0 * k.S + k.ix0 + k.dxmin;
 
+  // Cin-block pipeline: block 0's halo and the layer's BatchNorm constants are requested before anything else, so that their
+  // round trips run under the table set-up, the barrier and the weight-slab requests instead of one after the other.
+  constexpr int HS_P = PIPE ? conv_pipe_hslots(FW, TWF) : 1;
+  constexpr int kOOR = (int)0x80000000;        // beyond any num_records: the load returns zeros
+  ubr_u4 hv[HS_P];
+  int hoff[HS_P];
+  unsigned hok = 0u;
+  float xfr[PIPE ? 8 : 1];
+  const bool xf_early = PIPE && k.in_scale != nullptr && k.CU * ET<T>::CPU <= 512;
+  if constexpr (PIPE) {
+    const int c = tid & (k.UPB - 1);
+    const int nit = k.HH * (int)k.rw;
+    int hy = (int)__umulhi((unsigned)tid, k.rw_magic);
+    int j = tid - hy * (int)k.rw;
+#pragma unroll
+    for (int u = 0; u < HS_P; ++u) {
+      const int iy = hy0 + hy, ix = hx0 + (j >> k.lgUPB);
+      const bool ok = (tid + u * 256 < nit) && (unsigned)iy < (unsigned)k.H && (unsigned)ix < (unsigned)k.W;
+      hoff[u] = ok ? iy * k.x_sy32 + ix * k.x_sx32 + c * 16 : kOOR;
+      hok |= ok ? (1u << u) : 0u;
+      j += k.step_j; hy += k.step_hy;
+      if (j >= (int)k.rw) { j -= (int)k.rw; hy += 1; }
+    }
+    const __amdgpu_buffer_rsrc_t xr0 = __builtin_amdgcn_make_buffer_rsrc((void*)(k.x + (long)n * k.x_sn), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int u = 0; u < HS_P; ++u) hv[u] = __builtin_amdgcn_raw_buffer_load_b128(xr0, hoff[u], 0, 0);
+    if (xf_early) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int ch = tid + i * 256;
+        const bool in = ch < k.CU * ET<T>::CPU;
+        xfr[4 * i + 0] = in ? k.in_sub[ch] : 0.f; xfr[4 * i + 1] = in ? k.in_scale[ch] : 0.f;
+        xfr[4 * i + 2] = in ? k.in_shift[ch] : 0.f; xfr[4 * i + 3] = in ? k.in_lo[ch] : 0.f;
+      }
+    }
+  }
   for (int u = tid; u < 4 * k.steps; u += 256) {
     int off = 0;
     if (u < k.nunits) {
@@ -160,54 +196,53 @@ __global__ __launch_bounds__(256, ((NT == 4 && FW <= 2 && !PIPE) ? 4 : 2)) void 
     // guarded loads per block, 17.2 k the BatchNorm transform + LDS stores, 0.07 k waiting for data).  So the per-block
     // bookkeeping is done ONCE per workgroup: a slot's source offset (buffer load, out-of-range = zero padding), its
     // validity bit and its LDS address do not depend on the cin block; the block only moves a scalar offset.
-    constexpr int HS = conv_pipe_hslots(FW, TWF), WS = conv_pipe_wslots(NT);
-    constexpr int kOOR = (int)0x80000000;        // beyond any num_records: the load returns zeros
-    ubr_u4 hv[HS], wv[WS];
+    constexpr int HS = HS_P, WS = conv_pipe_wslots(NT);
+    ubr_u4 wv[WS];
     const int c = tid & (k.UPB - 1);
     const int nw = 4 * k.steps * TN;
-    int hoff[HS], woff[WS];
-    unsigned hok = 0u;
-    {
-      int hy = (int)__umulhi((unsigned)tid, k.rw_magic);
-      int j = tid - hy * (int)k.rw;
+    int woff[WS];
 #pragma unroll
-      for (int u = 0; u < HS; ++u) {
-        const int iy = hy0 + hy, ix = hx0 + (j >> k.lgUPB);
-        const bool ok = (tid + u * 256 < nitems) && (unsigned)iy < (unsigned)k.H && (unsigned)ix < (unsigned)k.W;
-        hoff[u] = ok ? iy * k.x_sy32 + ix * k.x_sx32 + c * 16 : kOOR;
-        hok |= ok ? (1u << u) : 0u;
-        j += k.step_j; hy += k.step_hy;
-        if (j >= (int)k.rw) { j -= (int)k.rw; hy += 1; }
+    for (int u = 0; u < WS; ++u) {
+      const int i = tid + u * 256;
+      int v = kOOR;
+      if (i < nw) {
+        const int src = wsrc[i / TN];
+        if (src >= 0) v = (src + n0 + (i % TN)) * 16;
       }
-#pragma unroll
-      for (int u = 0; u < WS; ++u) {
-        const int i = tid + u * 256;
-        int v = kOOR;
-        if (i < nw) {
-          const int src = wsrc[i / TN];
-          if (src >= 0) v = (src + n0 + (i % TN)) * 16;
-        }
-        woff[u] = v;
-      }
+      woff[u] = v;
     }
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)xn, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)k.w, 0, 0x7fffffff, 0x00020000);
     // BatchNorm constants of every input channel, [unit][sub | scale | shift | lo][CPU] in LDS: a thread's block constants are
     // 4 * CPU consecutive floats
     float* xfc = reinterpret_cast<float*>(smem + k.xfc_off);
-    if (has_xf) {
-      for (int ch = tid; ch < k.CU * CPU; ch += 256) {
-        float* o = xfc + (ch / CPU) * 4 * CPU + (ch % CPU);
-        o[0] = k.in_sub[ch]; o[CPU] = k.in_scale[ch]; o[2 * CPU] = k.in_shift[ch]; o[3 * CPU] = k.in_lo[ch];
-      }
-    }
-    auto load_blk = [&](int blk) {
+    auto load_blk = [&](int blk, bool halo_too = true) {
       const int sh = blk * k.UPB * 16, sw = blk * k.UPB * k.Cout_pad * 16;
+      if (halo_too) {
 #pragma unroll
-      for (int u = 0; u < HS; ++u) hv[u] = __builtin_amdgcn_raw_buffer_load_b128(xr, hoff[u], sh, 0);
+        for (int u = 0; u < HS; ++u) hv[u] = __builtin_amdgcn_raw_buffer_load_b128(xr, hoff[u], sh, 0);
+      }
 #pragma unroll
       for (int u = 0; u < WS; ++u) wv[u] = __builtin_amdgcn_raw_buffer_load_b128(wr, woff[u], sw, 0);
     };
+    load_blk(0, false);        // block 0's weight slab (its halo has been in flight since the top of the kernel)
+    if (has_xf) {
+      if (xf_early) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int ch = tid + i * 256;
+          if (ch < k.CU * CPU) {
+            float* o = xfc + (ch / CPU) * 4 * CPU + (ch % CPU);
+            o[0] = xfr[4 * i + 0]; o[CPU] = xfr[4 * i + 1]; o[2 * CPU] = xfr[4 * i + 2]; o[3 * CPU] = xfr[4 * i + 3];
+          }
+        }
+      } else {
+        for (int ch = tid; ch < k.CU * CPU; ch += 256) {
+          float* o = xfc + (ch / CPU) * 4 * CPU + (ch % CPU);
+          o[0] = k.in_sub[ch]; o[CPU] = k.in_scale[ch]; o[2 * CPU] = k.in_shift[ch]; o[3 * CPU] = k.in_lo[ch];
+        }
+      }
+    }
     // complete slots (every thread has an item) / the partial one: wave-uniform tests in front of the LDS writes
     const int hfull = nitems >> 8, hrem = nitems & 255, wfull = nw >> 8, wrem = nw & 255;
     char* const halo_w = halo + (tid >> k.lgUPB) * k.pixb + c * 16;
@@ -250,7 +285,6 @@ __global__ __launch_bounds__(256, ((NT == 4 && FW <= 2 && !PIPE) ? 4 : 2)) void 
 #else
 #define UBR_STAMP(acc_) do { } while (0)
 #endif
-    load_blk(0);
     UBR_STAMP(tL);
     for (int blk = 0; blk < k.nblk; ++blk) {
       __syncthreads();          // previous block's fragments fully read (block 0: the constants above are visible)
