@@ -58,13 +58,13 @@ elif what.startswith("wgrad"):
     x, g = mk(N, HW, HW, Cin), mk(N, HW, HW, Cout)
     dW = torch.empty(Cout, Cin, k, k, device=dev)
     ws = ops.WgradWorkspace()
-    xfw = aff(Cin)
+    xfw = aff(Cin) if "noxf" not in sys.argv else None
     taps = ops.conv_taps(k, 1, k // 2)
     if "kernelonly" in sys.argv:      # time ubr_wgrad alone (no slab reduction)
         import ctypes as C
         from ubresnet_amd import _lib as L
         d = L.WgradDesc(); d.dtype = L.dtype_id(dt); d.N, d.H, d.W, d.Cin = N, HW, HW, Cin
-        d.x = ops._tv(x); d.xf = ops._xf(xfw); d.GH, d.GW, d.Cout = HW, HW, Cout; d.g = ops._tv(g); d.ntaps = len(taps)
+        d.x = ops._tv(x); d.xf = ops._xf(xfw) if xfw is not None else d.xf; d.GH, d.GW, d.Cout = HW, HW, Cout; d.g = ops._tv(g); d.ntaps = len(taps)
         for i, t in enumerate(taps): d.dy[i], d.dx[i] = t[0], t[1]
         d.S, d.iy0, d.ix0 = 1, 0, 0
         ns, nb = C.c_int32(0), C.c_int64(0)
@@ -80,8 +80,8 @@ elif what.startswith("wgrad"):
             st = st[st[:, 4] > 0]
             if len(st):
                 m = st.float().median(0).values
-                print("stamps (median cycles per workgroup over %d WGs): store+barriers %d, load issue %d, compute %d, epilogue %d, total %d; start spread %d"
-                      % (len(st), m[0], m[1], m[2], m[3], m[4], int(st[:, 5].max() - st[:, 5].min())))
+                print("stamps (median cycles per workgroup over %d WGs): transform+LDS store %d, barriers %d, load wait %d, load issue %d, compute %d, epilogue %d, total %d"
+                      % (len(st), m[0], m[6], m[7], m[1], m[2], m[3], m[4]))
         atexit.register(_dump)
     else:
         fn = lambda: ops.wgrad(x, g, taps, dW, Cin * k * k, k * k, Cout, Cin, ws, xf=xfw)

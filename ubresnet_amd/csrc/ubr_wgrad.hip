@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256, (TPG == 25 ? 2 : 1)) void wgrad_kernel(const W
   const int G = gridDim.x;
   int cur = blockIdx.x;
 #ifdef UBR_WGRAD_STAMPS
-  unsigned long long tS = 0, tL = 0, tC = 0, t_;
+  unsigned long long tS = 0, tL = 0, tC = 0, tB = 0, tW = 0, t_;
 #define UBR_STAMP(acc_) do { unsigned long long n_ = __builtin_amdgcn_s_memtime(); acc_ += n_ - t_; t_ = n_; } while (0)
   const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
   t_ = t_begin;
@@ -294,9 +294,15 @@ __global__ __launch_bounds__(256, (TPG == 25 ? 2 : 1)) void wgrad_kernel(const W
     UBR_STAMP(tL);
     while (cur < k.ntiles) {
       __syncthreads();     // previous tile fully consumed
+#ifdef UBR_WGRAD_STAMPS
+      UBR_STAMP(tB);
+      asm volatile("s_waitcnt vmcnt(9)" ::: "memory");        // (GS + XS loads of the other register set may stay in flight)
+      UBR_STAMP(tW);
+#endif
       store_tile(gvA, xvA, xokA);
-      __syncthreads();
       UBR_STAMP(tS);
+      __syncthreads();
+      UBR_STAMP(tB);
       if (cur + 2 * G < k.ntiles) load_tile(gvA, xvA, xokA);      // in flight during two MFMA phases
       UBR_STAMP(tL);
       compute_tile();
@@ -304,9 +310,15 @@ __global__ __launch_bounds__(256, (TPG == 25 ? 2 : 1)) void wgrad_kernel(const W
       cur += G;
       if (cur >= k.ntiles) break;
       __syncthreads();
+#ifdef UBR_WGRAD_STAMPS
+      UBR_STAMP(tB);
+      asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+      UBR_STAMP(tW);
+#endif
       store_tile(gvB, xvB, xokB);
-      __syncthreads();
       UBR_STAMP(tS);
+      __syncthreads();
+      UBR_STAMP(tB);
       if (cur + 2 * G < k.ntiles) load_tile(gvB, xvB, xokB);
       UBR_STAMP(tL);
       compute_tile();
@@ -377,7 +389,7 @@ __global__ __launch_bounds__(256, (TPG == 25 ? 2 : 1)) void wgrad_kernel(const W
   if (k.stamps != nullptr && tid == 0) {
     const unsigned long long t_end = __builtin_amdgcn_s_memtime();
     unsigned long long* o = k.stamps + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8;
-    o[0] = tS; o[1] = tL; o[2] = tC; o[3] = t_end - t_; o[4] = t_end - t_begin; o[5] = t_begin;
+    o[0] = tS; o[1] = tL; o[2] = tC; o[3] = t_end - t_; o[4] = t_end - t_begin; o[5] = t_begin; o[6] = tB; o[7] = tW;
   }
 #endif
 }
