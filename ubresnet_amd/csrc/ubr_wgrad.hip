@@ -62,8 +62,12 @@ __device__ __forceinline__ uint4 sc_frag32(const char* p0, int pstride) {
 // 8-row tiles when waves split rows, 4-row tiles when they split channels, 7x7 for the 25-tap kernel) instead of the
 // worst case; the planner shrinks the tile height for dilated / strided layers until their halo fits.
 // BIGX variants (9-tap, Cout tile 16 only: the ASPP branches and the column-expanded stem) carry 12 slots.
-__host__ __device__ constexpr int wgrad_xslots(bool nsplit, int tpg, int nb, int cpu, bool bigx) {
-  return (bigx ? 12 : (nsplit ? 7 : (tpg == 25 ? 5 : (nb == 1 ? 3 : 6)))) * (8 / cpu);
+// The wide 9-tap tile (N-split, MA = 2) walks 8-row pixel tiles: 10 halo rows for 8 output rows instead of 6 for 4 (the BatchNorm
+// transform of the halo was 22 % of that kernel, in-kernel stamps), half as many barrier pairs and tile set-ups; its 11 + 4 slots
+// replace the two 7 + 2 slot sets of the two-tiles-ahead prefetch (one 8-row MFMA phase covers a load round trip).
+__host__ __device__ constexpr bool wgrad_tall(bool nsplit, int tpg, int ma) { return nsplit && tpg == 9 && ma == 2; }
+__host__ __device__ constexpr int wgrad_xslots(bool nsplit, int tpg, int nb, int cpu, bool bigx, int ma = 0) {
+  return (bigx ? 12 : (wgrad_tall(nsplit, tpg, ma) ? 11 : (nsplit ? 7 : (tpg == 25 ? 5 : (nb == 1 ? 3 : 6))))) * (8 / cpu);
 }
 
 template <typename T, int MA, int NB, int TPG, bool NSPLIT, bool BIGX>
@@ -99,8 +103,9 @@ __global__ __launch_bounds__(256, (TPG == 25 ? 2 : 1)) void wgrad_kernel(const W
   // ---- staging: each thread keeps ONE channel unit (256 % units-per-pixel == 0), so the BatchNorm constants
   // of its channels sit in registers.  The tile loop is software-pipelined: the global loads of tile i+1 are
   // issued into registers (gv/xv) right before the MFMA phase of tile i and written to LDS after it. ----
-  constexpr int GS = (NSPLIT ? 4 : 8) * 32 * UG / 256;       // G slots per thread (TH <= 4 / 8)
-  constexpr int XS = wgrad_xslots(NSPLIT, TPG, NB, CPU, BIGX);     // X slots per thread (host shrinks the tile until the halo fits)
+  constexpr bool TALL = wgrad_tall(NSPLIT, TPG, MA);
+  constexpr int GS = ((NSPLIT && !TALL) ? 4 : 8) * 32 * UG / 256;       // G slots per thread (TH <= 4 / 8)
+  constexpr int XS = wgrad_xslots(NSPLIT, TPG, NB, CPU, BIGX, MA);     // X slots per thread (host shrinks the tile until the halo fits)
   float xsub[CPU], xsc[CPU], xsh[CPU], xlo[CPU];
   if (has_xf) {
     const int ch0 = ci0 + (tid % UX) * CPU;
@@ -116,7 +121,7 @@ __global__ __launch_bounds__(256, (TPG == 25 ? 2 : 1)) void wgrad_kernel(const W
   // SIMD, every variant but the 25-tap one): with one workgroup per CU nothing else hides a load, and one tile's MFMA phase
   // (72 MFMAs per wave, ~0.5 us) is shorter than a round trip to HBM under load -- the wide 9-tap kernel spent more time
   // waiting for the next tile than computing.
-  constexpr bool DEEP = TPG != 25;
+  constexpr bool DEEP = TPG != 25 && !TALL;
   u32x4_t gvA[GS], xvA[XS], gvB[DEEP ? GS : 1], xvB[DEEP ? XS : 1];
   unsigned xokA = 0u, xokB = 0u;
 
@@ -418,7 +423,7 @@ static int wgrad_plan(const ubr_wgrad_desc* d, WPlan* p) {
   if (TPG <= 9 && d->Cout % 64 == 0 && d->Cin % 64 == 0) {   // wide layers: 64 x 64 channel tile, waves split cin
     static const int ma9 = [] { const char* e = getenv("UBR_WGRAD_MA9"); return e ? atoi(e) : 2; }();
     MA = (TPG == 9) ? ma9 : 4; NB = 4; p->nsplit_mode = 1;   // 9 taps: 32 x 64 tile keeps the kernel under 256 VGPRs (2 waves/SIMD)
-    p->TH = d->S == 1 ? 4 : 2;
+    p->TH = d->S == 1 ? (wgrad_tall(true, TPG, MA) ? 8 : 4) : 2;
   }
   {
     // the pipelined loop keeps one tile in registers: shrink the tile height, then the channel tile, until the
@@ -427,7 +432,7 @@ static int wgrad_plan(const ubr_wgrad_desc* d, WPlan* p) {
     const int th0 = p->TH;
     p->bigx = 0;
     for (;;) {
-      const int xs = wgrad_xslots(p->nsplit_mode != 0, TPG, NB, cpu, p->bigx != 0);
+      const int xs = wgrad_xslots(p->nsplit_mode != 0, TPG, NB, cpu, p->bigx != 0, MA);
       const int ux = NB * 16 / cpu;
       p->HH = (p->TH - 1) * d->S + 1 + (dymax - dymin);
       p->HW = 31 * d->S + 1 + (dxmax - dxmin);
