@@ -329,10 +329,16 @@ def main():
 
     # ---- per-launch breakdown of one more step (HIP events on the launch stream) -> roofline of the dominant kernel
     if not a.no_breakdown:
-        prof = ops.LaunchProfiler() if rank == 0 else None
+        # Launch tapes: the taped launches are timed INSIDE a replay (events around every launch on its own stream, same two-stream
+        # overlap as the timed steps and as the rocprofv3 run of this command); the few launches issued from Python (head,
+        # loss, stem expansion, optimizer) are timed by the operator wrappers as before.
+        from ubresnet_amd import plan as _plan
+        prof = ops.LaunchProfiler()
         ops._prof = prof
+        _plan.TIMED = prof.timed if _plan.ENABLED else None
         step()                      # every rank runs it: the step contains the gradient all-reduce
         ops._prof = None
+        _plan.TIMED = None
         torch.cuda.synchronize()
     if rank == 0 and not a.no_breakdown:
         # dominant KERNEL SYMBOL (as rocprofv3 --kernel-trace --stats names it): launches, average duration and the

@@ -338,6 +338,11 @@ int ubr_tape_mark(ubr_tape* t, int slot);                 /* >= 0: mark id; < 0:
 int ubr_tape_wait_mark(const ubr_tape* t, int mark, void* stream);
 int ubr_tape_size(const ubr_tape* t);
 int ubr_tape_replay(const ubr_tape* t, int nstreams, void* const* streams);
+/* tag the launches recorded from now on (label >= 0; -1 = none): the host's index of the operator call they belong to */
+int ubr_tape_set_label(ubr_tape* t, int label);
+/* replay with timing events around every launch on its own stream; synchronises the tape's streams.  ms[i], label[i] per
+   node (label -2: fork / mark node); cap = room in both arrays (>= ubr_tape_size) */
+int ubr_tape_replay_timed(const ubr_tape* t, int nstreams, void* const* streams, float* ms, int32_t* label, int cap);
 
 const char* ubr_last_error(void);
 int ubr_version(void);

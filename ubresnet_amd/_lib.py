@@ -91,7 +91,7 @@ SYMBOLS = [
     "ubr_logsoftmax_bwd", "ubr_pixelwise_nll_fwd", "ubr_pixelwise_nll_bwd", "ubr_confusion",
     "ubr_channel_sum", "ubr_cast_f64_to_f32", "ubr_zero", "ubr_adam_step", "ubr_sgd_step", "ubr_crop_tiles", "ubr_stitch_tiles", "ubr_last_error", "ubr_version",
     "ubr_tape_create", "ubr_tape_destroy", "ubr_tape_begin", "ubr_tape_end", "ubr_tape_pause", "ubr_tape_fork", "ubr_tape_mark",
-    "ubr_tape_wait_mark", "ubr_tape_size", "ubr_tape_replay",
+    "ubr_tape_wait_mark", "ubr_tape_size", "ubr_tape_replay", "ubr_tape_set_label", "ubr_tape_replay_timed",
 ]
 
 _lib = None
@@ -154,6 +154,8 @@ def _declare(lib):
     lib.ubr_tape_wait_mark.argtypes = [vp, i32, vp]
     lib.ubr_tape_size.argtypes = [vp]
     lib.ubr_tape_replay.argtypes = [vp, i32, C.POINTER(vp)]
+    lib.ubr_tape_set_label.argtypes = [vp, i32]
+    lib.ubr_tape_replay_timed.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(C.c_float), C.POINTER(C.c_int32), i32]
     for name in SYMBOLS:
         fn = getattr(lib, name)
         if name not in ("ubr_last_error", "ubr_version", "ubr_stem_wgrad_workspace", "ubr_conv_last_config", "ubr_wgrad_last_config",

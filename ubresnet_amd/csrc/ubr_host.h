@@ -46,6 +46,7 @@ struct ubr_tape {
     int kind, slot, slot2;
     std::function<void(hipStream_t)> fn;    // LAUNCH (kernels and memsets)
     hipEvent_t ev;                          // FORK / MARK
+    int label;                              // LAUNCH: the host's tag for this launch (ubr_tape_set_label), -1 = none
   };
   std::vector<Node> nodes;
   std::vector<hipEvent_t> marks;            // MARK events by id
@@ -53,6 +54,7 @@ struct ubr_tape {
   int nstreams = 0;
   bool recording = false, bad = false;
   int paused = 0;
+  int cur_label = -1;
   int slot_of(hipStream_t st) const {
     for (int i = 0; i < nstreams; ++i) if (rec[i] == st) return i;
     return -1;
@@ -60,7 +62,7 @@ struct ubr_tape {
   void push(hipStream_t st, std::function<void(hipStream_t)> fn) {
     const int s = slot_of(st);
     if (s < 0) { bad = true; return; }      // a launch on a stream the tape does not know: replay would be wrong
-    nodes.push_back(Node{LAUNCH, s, -1, std::move(fn), nullptr});
+    nodes.push_back(Node{LAUNCH, s, -1, std::move(fn), nullptr, cur_label});
   }
 };
 ubr_tape* ubr_tape_current();                // the tape recording on this thread (nullptr: none); ubr_tape.hip

@@ -62,7 +62,7 @@ extern "C" int ubr_tape_fork(ubr_tape* t, int from_slot, int to_slot) {
   hipEvent_t ev;
   int rc = new_event(&ev);
   if (rc != UBR_OK) return rc;
-  t->nodes.push_back(ubr_tape::Node{ubr_tape::FORK, from_slot, to_slot, nullptr, ev});
+  t->nodes.push_back(ubr_tape::Node{ubr_tape::FORK, from_slot, to_slot, nullptr, ev, -1});
   return UBR_OK;
 }
 
@@ -71,7 +71,7 @@ extern "C" int ubr_tape_mark(ubr_tape* t, int slot) {
   hipEvent_t ev;
   int rc = new_event(&ev);
   if (rc != UBR_OK) return rc;
-  t->nodes.push_back(ubr_tape::Node{ubr_tape::MARK, slot, (int)t->marks.size(), nullptr, ev});
+  t->nodes.push_back(ubr_tape::Node{ubr_tape::MARK, slot, (int)t->marks.size(), nullptr, ev, -1});
   t->marks.push_back(ev);
   return (int)t->marks.size() - 1;
 }
@@ -104,5 +104,56 @@ extern "C" int ubr_tape_replay(const ubr_tape* t, int nstreams, void* const* str
     }
   }
   UBR_LAUNCH_CHECK("ubr_tape_replay");
+  return UBR_OK;
+}
+
+extern "C" int ubr_tape_set_label(ubr_tape* t, int label) {
+  UBR_CHECK(t != nullptr && g_tape == t && t->recording, "ubr_tape_set_label: this tape is not recording on this thread");
+  t->cur_label = label;
+  return UBR_OK;
+}
+
+// Replay with a pair of timing events around every launch, on the launch's own stream: per-launch durations under the same
+// two-stream overlap as an ordinary replay (bench.py's breakdown; the Python-scheduled path paces the streams differently).
+// Synchronises the tape's streams before returning.  ms[i] / label[i] for node i; label -2 marks fork / mark nodes.
+extern "C" int ubr_tape_replay_timed(const ubr_tape* t, int nstreams, void* const* streams, float* ms, int32_t* label, int cap) {
+  UBR_CHECK(t != nullptr && !t->recording && !t->bad, "ubr_tape_replay_timed: tape is empty, recording or unusable");
+  UBR_CHECK(streams != nullptr && nstreams == t->nstreams && ms != nullptr && label != nullptr, "ubr_tape_replay_timed: bad arguments");
+  const int n = (int)t->nodes.size();
+  UBR_CHECK(cap >= n, "ubr_tape_replay_timed: %d nodes, room for %d", n, cap);
+  std::vector<hipEvent_t> e0(n, nullptr), e1(n, nullptr);
+  int rc = UBR_OK;
+  for (int i = 0; i < n && rc == UBR_OK; ++i) {
+    const auto& nd = t->nodes[i];
+    hipStream_t s = (hipStream_t)streams[nd.slot];
+    hipError_t e = hipSuccess;
+    if (nd.kind == ubr_tape::LAUNCH) {
+      e = hipEventCreate(&e0[i]);
+      if (e == hipSuccess) e = hipEventCreate(&e1[i]);
+      if (e == hipSuccess) e = hipEventRecord(e0[i], s);
+      if (e == hipSuccess) { nd.fn(s); e = hipEventRecord(e1[i], s); }
+      label[i] = nd.label;
+    } else if (nd.kind == ubr_tape::FORK) {
+      e = hipEventRecord(nd.ev, s);
+      if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)streams[nd.slot2], nd.ev, 0);
+      label[i] = -2; ms[i] = 0.f;
+    } else {
+      e = hipEventRecord(nd.ev, s);
+      label[i] = -2; ms[i] = 0.f;
+    }
+    if (e != hipSuccess) { ubr_set_error("ubr_tape_replay_timed: %s", hipGetErrorString(e)); rc = UBR_ELAUNCH; }
+  }
+  for (int i = 0; i < nstreams; ++i) (void)hipStreamSynchronize((hipStream_t)streams[i]);
+  for (int i = 0; i < n; ++i) {
+    if (e0[i] != nullptr && e1[i] != nullptr && rc == UBR_OK) {
+      float v = 0.f;
+      if (hipEventElapsedTime(&v, e0[i], e1[i]) != hipSuccess) v = 0.f;
+      ms[i] = v;
+    }
+    if (e0[i] != nullptr) (void)hipEventDestroy(e0[i]);
+    if (e1[i] != nullptr) (void)hipEventDestroy(e1[i]);
+  }
+  if (rc != UBR_OK) return rc;
+  UBR_LAUNCH_CHECK("ubr_tape_replay_timed");
   return UBR_OK;
 }

@@ -18,6 +18,7 @@ NEG_BIG = -3.0e38
 # Optional per-launch timing (bench.py's kernel breakdown): when set, every wrapped op records a
 # torch.cuda.Event pair on the current stream (the stream the kernels are launched on).
 _prof = None
+_rec_sink = None      # ubresnet_amd.plan.Recording while a launch tape records: operator calls tag their launches
 
 
 class LaunchProfiler:
@@ -25,6 +26,7 @@ class LaunchProfiler:
 
     def __init__(self):
         self.records = []
+        self.timed = []          # (op, kernel, shape, bytes, flops, seconds) from timed tape replays (ubresnet_amd.plan.TIMED)
 
     def summary(self, by="shape"):
         """aggregate -> {key: [launches, seconds, bytes, flops]}; by = 'shape' (op, shape) or 'kernel' (symbol)"""
@@ -35,6 +37,13 @@ class LaunchProfiler:
             a = agg.setdefault(k, [0, 0.0, 0, 0.0])
             a[0] += 1
             a[1] += e0.elapsed_time(e1) * 1e-3
+            a[2] += nbytes
+            a[3] += flops
+        for name, kern, sig, nbytes, flops, sec in self.timed:
+            k = (name, sig) if by == "shape" else kern
+            a = agg.setdefault(k, [0, 0.0, 0, 0.0])
+            a[0] += 1
+            a[1] += sec
             a[2] += nbytes
             a[3] += flops
         return agg
@@ -54,7 +63,8 @@ def _act_bytes(args):
 def _timed(name):
     def deco(fn):
         def wrapper(*args, **kwargs):
-            if _prof is None:
+            sink = _rec_sink
+            if _prof is None and sink is None:
                 return fn(*args, **kwargs)
             acts = [a for a in list(args) + list(kwargs.values()) if isinstance(a, torch.Tensor) and a.dim() == 4]
             sig = " ".join("x".join(map(str, a.shape)) for a in acts[:3])
@@ -64,10 +74,13 @@ def _timed(name):
                 sig += " taps%d" % ntaps
             if "S" in kwargs:
                 sig += " S%d" % kwargs["S"]
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+            lab = sink.label_begin() if sink is not None else -1
+            if _prof is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             r = fn(*args, **kwargs)
-            e1.record()
+            if _prof is not None:
+                e1.record()
             kern, flops = name, 0.0
             if name == "conv":
                 x, wp, y = args[0], args[1], args[2]
@@ -77,7 +90,10 @@ def _timed(name):
                 buf = C.create_string_buffer(160)
                 L.lib().ubr_conv_last_kernel(buf, 160)
                 kern = buf.value.decode()
-            _prof.records.append((name, kern, sig, _act_bytes(acts), flops, e0, e1))
+            if sink is not None:
+                sink.label_end(lab, (name, kern, sig, _act_bytes(acts), flops))
+            if _prof is not None:
+                _prof.records.append((name, kern, sig, _act_bytes(acts), flops, e0, e1))
             return r
         wrapper.__name__ = fn.__name__
         wrapper.__doc__ = fn.__doc__
@@ -291,18 +307,22 @@ def wgrad(x: torch.Tensor, g: torch.Tensor, taps, dst: torch.Tensor, sm: int, sk
     d.slabs = slabs.data_ptr()
     d.nsplit = nsplit.value
     st = L.stream_ptr() if stream is None else stream.cuda_stream
+    sink = _rec_sink
     if _prof is not None:
         e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         e0.record(stream)
+    lab0 = sink.label_begin() if sink is not None else -1
     L.check(lib.ubr_wgrad(C.byref(d), st), "wgrad")
     if _prof is not None:
         e1.record(stream)
+    lab1 = sink.label_begin() if sink is not None else -1
     idx = _tap_arrays_w(taps)[2]
     assert dst.dtype == torch.float32
     L.check(lib.ubr_wgrad_reduce(slabs.data_ptr(), nsplit.value, len(taps), d.Cout, Cin, Cout_valid, Cin_valid,
                                  dst.data_ptr() + 4 * dst_offset, sm, sk, idx, 1 if accumulate else 0, st), "wgrad_reduce")
-    if _prof is not None:
-        e2.record(stream)
+    if _prof is not None or sink is not None:
+        if _prof is not None:
+            e2.record(stream)
         a, b, c, dd, bx = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
         lib.ubr_wgrad_last_config(C.byref(a), C.byref(b), C.byref(c), C.byref(dd), C.byref(bx))
         kern = "wgrad_kernel<%s, %d, %d, %d, %s, %s>" % (_DT_NAME[x.dtype], a.value, b.value, c.value, "true" if dd.value else "false",
@@ -310,8 +330,13 @@ def wgrad(x: torch.Tensor, g: torch.Tensor, taps, dst: torch.Tensor, sm: int, sk
         sig = "%s %s taps%d S%d" % ("x".join(map(str, x.shape)), "x".join(map(str, g.shape)), len(taps), S)
         nbytes = (x.numel() + g.numel()) * x.element_size()
         flops = 2.0 * g.shape[0] * g.shape[1] * g.shape[2] * g.shape[3] * Cin * len(taps)
-        _prof.records.append(("wgrad", kern, sig, nbytes, flops, e0, e1))
-        _prof.records.append(("wgrad_reduce", "wgrad_reduce_kernel (+stage1)", sig, nsplit.value * len(taps) * d.Cout * Cin * 4, 0.0, e1, e2))
+        red = ("wgrad_reduce", "wgrad_reduce_kernel (+stage1)", sig, nsplit.value * len(taps) * d.Cout * Cin * 4, 0.0)
+        if sink is not None:
+            sink.labels[lab0] = ("wgrad", kern, sig, nbytes, flops)
+            sink.label_end(lab1, red)
+        if _prof is not None:
+            _prof.records.append(("wgrad", kern, sig, nbytes, flops, e0, e1))
+            _prof.records.append(red + (e1, e2))
 
 
 # ------------------------------------------------------------------------------------------

@@ -29,6 +29,7 @@ from . import _lib as L
 
 ENABLED = os.environ.get("UBR_PLAN", "1") != "0"
 MAX_PLANS = 4
+TIMED = None      # a list: replays time every launch and append (op, kernel, shape, bytes, flops, seconds) per operator call (bench.py)
 
 
 class Tape:
@@ -76,6 +77,16 @@ class Tape:
     def size(self) -> int:
         return L.lib().ubr_tape_size(self.h)
 
+    def set_label(self, label: int):
+        L.check(L.lib().ubr_tape_set_label(self.h, label), "tape_set_label")
+
+    def replay_timed(self, streams):
+        """-> ([ms per node], [label per node]); label -2 = fork / mark node, -1 = launch outside any labelled operator"""
+        n = self.size()
+        ms, lab = (C.c_float * n)(), (C.c_int32 * n)()
+        L.check(L.lib().ubr_tape_replay_timed(self.h, len(streams), self._arr(streams), ms, lab, n), "tape_replay_timed")
+        return list(ms), list(lab)
+
 
 class TapeMark:
     """a point of a replayed stream another stream can wait for (the data-parallel reducer's exchange stream)"""
@@ -98,6 +109,30 @@ class Recording:
         self.stages = []         # backward: (lo, hi, mark on the compute stream, mark on the side stream or None)
         self.pre = None          # callable(s) issued from Python before a replay
         self.post = None         # ... and after it
+        self.labels = []         # per labelled operator call: (op, kernel symbol, shape signature, algorithmic bytes, flops)
+
+    def label_begin(self) -> int:
+        self.labels.append(None)
+        self.tape.set_label(len(self.labels) - 1)
+        return len(self.labels) - 1
+
+    def label_end(self, idx: int, meta):
+        self.labels[idx] = meta
+        self.tape.set_label(-1)
+
+    def replay(self, streams):
+        """ordinary replay, or -- while `TIMED` collects -- a replay with timing events around every launch"""
+        if TIMED is None:
+            self.tape.replay(streams)
+            return
+        ms, lab = self.tape.replay_timed(streams)
+        per = {}
+        for t, l in zip(ms, lab):
+            if l >= -1:
+                per[l] = per.get(l, 0.0) + t * 1e-3
+        for l, sec in per.items():
+            meta = self.labels[l] if l >= 0 and self.labels[l] is not None else ("other", "launches outside the timed operators (finalize kernels, memsets)", "", 0, 0.0)
+            TIMED.append(meta + (sec,))
 
 
 class PlannedPass:
@@ -124,7 +159,7 @@ def _streams(eng, dev):
 
 def usable(eng, x) -> bool:
     from . import ops
-    return (ENABLED and eng.kind in ("uresnet", "aspp") and x.is_cuda and ops._prof is None
+    return (ENABLED and eng.kind in ("uresnet", "aspp") and x.is_cuda and (ops._prof is None or TIMED is not None)
             and not torch.cuda.is_current_stream_capturing())
 
 
@@ -154,9 +189,12 @@ def forward(eng, x, training, dt, save):
         rec = Recording(len(streams))
         eng._rec = rec
         rec.tape.begin(streams)
+        from . import ops
+        ops._rec_sink = rec
         try:
             out, sv = eng.forward_eager(x, training, dt, save)
         finally:
+            ops._rec_sink = None
             eng._rec = None
             rec.tape.end()
         plan.fwd, plan.sv = rec, sv
@@ -164,7 +202,7 @@ def forward(eng, x, training, dt, save):
     else:
         x = eng._check_input(x, eng.model.conv1.in_channels)
         plan.fwd.pre(x)
-        plan.fwd.tape.replay(streams)
+        plan.fwd.replay(streams)
         out = plan.fwd.post()
         eng._bwd_packed = None           # (an eager backward after a replayed forward repacks its own weight images)
         sv = plan.sv
@@ -192,9 +230,12 @@ def backward(eng, sv, g_out, grad_ready, allow_plan=True):
             rec = Recording(len(streams))
             eng._rec = rec
             rec.tape.begin(streams)
+            from . import ops
+            ops._rec_sink = rec
             try:
                 flat, views = eng.backward_eager(sv, g_out, grad_ready)
             finally:
+                ops._rec_sink = None
                 eng._rec = None
                 rec.tape.end()
             plan.bwd, plan.flat, plan.views = rec, flat, views
@@ -202,7 +243,7 @@ def backward(eng, sv, g_out, grad_ready, allow_plan=True):
         if not g_out.is_contiguous():
             g_out = g_out.contiguous()
         plan.bwd.pre(g_out, sv.out)
-        plan.bwd.tape.replay(streams)
+        plan.bwd.replay(streams)
         if grad_ready is not None:
             for lo, hi, m0, m1 in plan.bwd.stages:
                 marks = (TapeMark(plan.bwd.tape, m0),) + ((TapeMark(plan.bwd.tape, m1),) if m1 is not None else ())
