@@ -123,3 +123,45 @@ def test_plan_steps_aside_when_replay_is_not_safe(monkeypatch):
     crit(m(x), lab, wgt).backward()
     assert torch.equal(grads(), ga)
     assert next(iter(eng._planned.values())) is not before
+
+
+def test_timed_replay_times_every_operator_and_changes_nothing(monkeypatch):
+    """bench.py's breakdown: with plan.TIMED set, a replay brackets every taped launch with timing events on its own stream
+    (ubr_tape_replay_timed) and reports one record per labelled operator call; the results of the step are those of an
+    ordinary replay."""
+    from ubresnet_amd import ops
+    monkeypatch.setattr(plan, "ENABLED", True)
+    m, planes = _make("uresnet", torch.bfloat16)
+    crit = PixelWiseNLLLoss()
+    x, lab, wgt = synthetic.make_batch(2, 64, 96, 1234, planes=planes)
+    xt, lt, wt = torch.from_numpy(x).cuda(), torch.from_numpy(lab).cuda(), torch.from_numpy(wgt).cuda()
+
+    def step():
+        m.zero_grad()
+        out = m(xt)
+        crit(out, lt, wt).backward()
+        torch.cuda.synchronize()
+        return out.detach().clone(), {n: p.grad.clone() for n, p in m.named_parameters()}
+
+    m.bn1.momentum = 0.0
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.momentum = 0.0          # (running statistics do not enter train-mode outputs; keep the steps identical anyway)
+    step()                               # records
+    o_ref, g_ref = step()                # ordinary replay
+    prof = ops.LaunchProfiler()
+    monkeypatch.setattr(ops, "_prof", prof)
+    monkeypatch.setattr(plan, "TIMED", prof.timed)
+    o_t, g_t = step()
+    monkeypatch.setattr(ops, "_prof", None)
+    monkeypatch.setattr(plan, "TIMED", None)
+    assert torch.equal(o_ref, o_t)
+    for n in g_ref:
+        assert torch.equal(g_ref[n], g_t[n]), n
+    names = {r[0] for r in prof.timed}
+    assert {"conv", "wgrad", "wgrad_reduce", "block_tail_fwd", "block_tail_bwd_apply", "bn_bwd_reduce", "maxpool_fwd"} <= names, names
+    assert len(prof.timed) > 150 and all(r[5] > 0.0 for r in prof.timed)
+    by_kernel = prof.summary(by="kernel")
+    assert any(k.startswith("wgrad_kernel<bf16_t") for k in by_kernel) and any(k.startswith("conv_") for k in by_kernel)
+    o_after, _ = step()                  # and ordinary replays keep working afterwards
+    assert torch.equal(o_ref, o_after)
