@@ -147,7 +147,23 @@ class PlannedPass:
 
 
 def _signature(model):
-    return tuple(t.data_ptr() for t in model.parameters()) + tuple(t.data_ptr() for t in model.buffers())
+    """device addresses of every parameter and buffer: a plan bakes them in, so a replaced storage or a replaced Parameter
+    must retire it.  The module list is walked once (the executor assumes a fixed module tree anyway: its gradient layout is
+    built from it); per call only the modules' own parameter / buffer dicts are read -- model.parameters() + model.buffers()
+    re-walk the tree through three generator layers and cost ~0.35 ms per call, twice per step."""
+    mods = model.__dict__.get("_ubr_modules")
+    if mods is None:
+        mods = [m for m in model.modules() if m._parameters or m._buffers]
+        model.__dict__["_ubr_modules"] = mods
+    sig = []
+    for m in mods:
+        for t in m._parameters.values():
+            if t is not None:
+                sig.append(t.data_ptr())
+        for t in m._buffers.values():
+            if t is not None:
+                sig.append(t.data_ptr())
+    return tuple(sig)
 
 
 def _streams(eng, dev):
