@@ -374,10 +374,13 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const PoolK k) {
   const long npix = (long)k.N * k.OH * k.OW;
 #pragma unroll 2
   for (long p = ix.p; p < npix; p += ix.pstep) {
-    const int ox = (int)(p % k.OW);
-    const long r = p / k.OW;
-    const int oy = (int)(r % k.OH);
-    const int n = (int)(r / k.OH);
+    // (pixel counts are < 2^31: the host checks tensor sizes; 32-bit division is a third of the 64-bit sequence)
+    const unsigned pu = (unsigned)p, ru = pu / (unsigned)k.OW;
+    const int ox = (int)(pu - ru * (unsigned)k.OW);
+    const int n = (int)(ru / (unsigned)k.OH);
+    const int oy = (int)(ru - (unsigned)n * (unsigned)k.OH);
+    const long r = (long)ru;
+    (void)r;
     float m[CPU];
     int am[CPU];
 #pragma unroll
@@ -430,10 +433,13 @@ __global__ __launch_bounds__(256) void maxpool_bwd_s2_amax_kernel(const PoolK k)
   const long npix = (long)k.N * k.OH * k.OW;
 #pragma unroll 2
   for (long p = ix.p; p < npix; p += ix.pstep) {
-    const int ox = (int)(p % k.OW);
-    const long r = p / k.OW;
-    const int oy = (int)(r % k.OH);
-    const int n = (int)(r / k.OH);
+    // (pixel counts are < 2^31: the host checks tensor sizes; 32-bit division is a third of the 64-bit sequence)
+    const unsigned pu = (unsigned)p, ru = pu / (unsigned)k.OW;
+    const int ox = (int)(pu - ru * (unsigned)k.OW);
+    const int n = (int)(ru / (unsigned)k.OH);
+    const int oy = (int)(ru - (unsigned)n * (unsigned)k.OH);
+    const long r = (long)ru;
+    (void)r;
     float g[2][2][CPU];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -556,10 +562,13 @@ __global__ __launch_bounds__(256) void maxpool_bwd_s2_kernel(const PoolK k) {
   const long npix = (long)k.N * k.OH * k.OW;
 #pragma unroll 2
   for (long p = ix.p; p < npix; p += ix.pstep) {
-    const int ox = (int)(p % k.OW);
-    const long r = p / k.OW;
-    const int oy = (int)(r % k.OH);
-    const int n = (int)(r / k.OH);
+    // (pixel counts are < 2^31: the host checks tensor sizes; 32-bit division is a third of the 64-bit sequence)
+    const unsigned pu = (unsigned)p, ru = pu / (unsigned)k.OW;
+    const int ox = (int)(pu - ru * (unsigned)k.OW);
+    const int n = (int)(ru / (unsigned)k.OH);
+    const int oy = (int)(ru - (unsigned)n * (unsigned)k.OH);
+    const long r = (long)ru;
+    (void)r;
     float g[2][2][CPU];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
