@@ -268,7 +268,7 @@ def main():
         opt = FlatAdam(model, lr=1e-5, weight_decay=1e-4)
     else:
         opt = torch.optim.Adam(params, lr=1e-5, weight_decay=1e-4, fused=True)
-    reducer = GradAllReducer(model) if dist.is_initialized() else None
+    reducer = GradAllReducer(model, bucket_bytes=int(float(os.environ.get("UBR_BUCKET_MB", "8")) * (1 << 20))) if dist.is_initialized() else None
 
     # synthetic crops: rank r holds images [r*b, (r+1)*b) of the global batch, resident in HBM
     gb = a.batch * world
