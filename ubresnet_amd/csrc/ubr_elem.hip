@@ -350,7 +350,12 @@ __global__ void cast_f64_kernel(const double* src, float* dst, int n, int stride
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   double a = 0.0;
-  for (int sl = 0; sl < slots; ++sl) a += src[(size_t)sl * stride + i];
+  if (slots == UBR_STAT_SLOTS) {      // the striped accumulators: every slot load in flight at once (see bn_finalize_kernel)
+#pragma unroll
+    for (int sl = 0; sl < UBR_STAT_SLOTS; ++sl) a += src[(size_t)sl * stride + i];
+  } else {
+    for (int sl = 0; sl < slots; ++sl) a += src[(size_t)sl * stride + i];
+  }
   const float v = (float)(a * scale);
   dst[i] = accumulate ? dst[i] + v : v;
 }
