@@ -158,6 +158,8 @@ typedef struct {
   int32_t S, iy0, ix0;
   float* slabs;              /* workspace, >= ubr_wgrad_workspace() bytes */
   int32_t nsplit;            /* number of pixel splits (slabs); from ubr_wgrad_plan */
+  int32_t exclusive;         /* nonzero: nothing else runs beside this launch (the last weight gradient of a backward pass): fill
+                                the GPU (three workgroups per CU, narrow staging) instead of leaving room for the compute stream */
 } ubr_wgrad_desc;
 
 /* returns the number of slabs the launch will use for this shape (>=1) and the workspace bytes */

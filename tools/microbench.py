@@ -26,7 +26,7 @@ def aff(C):
 
 cfgs = {"conv16": (512, 16, 16, 3), "conv32": (256, 32, 32, 3), "conv64": (128, 64, 64, 3), "conv7": (512, 16, 16, 7),
         "conv1x1": (512, 16, 32, 1), "conv1x1b": (512, 32, 16, 1), "conv128": (64, 128, 128, 3), "conv256": (32, 256, 256, 3), "conv512": (16, 512, 512, 3),
-        "wgrad16": (512, 16, 16, 3), "wgrad32": (256, 32, 32, 3), "wgrad64": (128, 64, 64, 3), "wgrad256": (32, 256, 256, 3)}
+        "wgrad16": (512, 16, 16, 3), "wgrad32": (256, 32, 32, 3), "wgrad64": (128, 64, 64, 3), "wgrad256": (32, 256, 256, 3), "wgradstem": (512, 16, 16, 7)}
 if what.startswith("conv"):
     HW, Cin, Cout, k = cfgs[what]
     x, y = mk(N, HW, HW, Cin), torch.empty((N, HW, HW, Cout), dtype=dt, device=dev)
@@ -60,6 +60,8 @@ elif what.startswith("wgrad"):
     ws = ops.WgradWorkspace()
     xfw = aff(Cin) if "noxf" not in sys.argv else None
     taps = ops.conv_taps(k, 1, k // 2)
+    if what == "wgradstem":       # the column-expanded stem: 7 vertical taps over 16 channels at full resolution
+        taps = [(dy, 0, dy + 3) for dy in range(-3, 4)]
     if "kernelonly" in sys.argv:      # time ubr_wgrad alone (no slab reduction)
         import ctypes as C
         from ubresnet_amd import _lib as L

@@ -78,6 +78,7 @@ class WgradDesc(C.Structure):
         ("S", C.c_int32), ("iy0", C.c_int32), ("ix0", C.c_int32),
         ("slabs", C.c_void_p),
         ("nsplit", C.c_int32),
+        ("exclusive", C.c_int32),
     ]
 
 

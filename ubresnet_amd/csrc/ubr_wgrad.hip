@@ -438,7 +438,8 @@ static int wgrad_plan(const ubr_wgrad_desc* d, WPlan* p) {
       p->HW = 31 * d->S + 1 + (dxmax - dxmin);
       if ((long)p->HH * p->HW * ux <= 256L * xs) break;
       // more slots before a shorter tile, where the wide-slot variant exists
-      if (!p->bigx && !p->nsplit_mode && MA == 1 && TPG == 9) { p->bigx = 1; continue; }
+      // (an exclusive launch prefers a shorter tile on the narrow-slot variant: 158 instead of 269 registers, three waves per SIMD)
+      if (!d->exclusive && !p->bigx && !p->nsplit_mode && MA == 1 && TPG == 9) { p->bigx = 1; continue; }
       if (p->TH > 1) { p->TH /= 2; continue; }
       if (p->nsplit_mode) { p->nsplit_mode = 0; MA = 2; NB = 2; p->TH = d->S == 1 ? 8 : 4; continue; }
       if (NB > 1) { NB = 1; p->bigx = 0; p->TH = th0 > 4 ? 4 : th0; continue; }
@@ -473,7 +474,9 @@ static int wgrad_plan(const ubr_wgrad_desc* d, WPlan* p) {
   // file and LDS for the compute stream's kernels: 512 / 1024 workgroups cost the step 5 % (1077 vs 1136 img/s).
   static const int tgt_n = [] { const char* e = getenv("UBR_WGRAD_TARGET_N"); return e ? atoi(e) : 256; }();
   static const int tgt_k = [] { const char* e = getenv("UBR_WGRAD_TARGET_K"); return e ? atoi(e) : 256; }();
-  int target = (p->nsplit_mode ? tgt_n : tgt_k) / (p->gy * p->gz);
+  // an exclusive launch (the stem's weight gradient closes the backward pass: the compute stream is idle by then) takes three
+  // workgroups per CU: 188 -> 88 us for the 7-tap 16-channel layer at 16x512x512
+  int target = (d->exclusive ? 768 : (p->nsplit_mode ? tgt_n : tgt_k)) / (p->gy * p->gz);
   if (target < 1) target = 1;
   // bound slab memory: at most 64 MiB of partials per launch
   const size_t slab_bytes = (size_t)d->ntaps * d->Cout * d->Cin * sizeof(float);

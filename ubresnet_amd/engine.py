@@ -541,7 +541,8 @@ class Engine:
         dW = G(conv1.weight)
         taps = [(ky - 3, 0, 7 * ky) for ky in range(7)]
         for ci in range(Cin):
-            self._wg(x16[..., 16 * ci:16 * ci + 16], g_c0, taps, dW, Cin * 49, 1, Cout, 7, self.wws, dst_offset=ci * 49)
+            # the last launch(es) of a backward pass: the compute stream has nothing left to run beside them
+            self._wg(x16[..., 16 * ci:16 * ci + 16], g_c0, taps, dW, Cin * 49, 1, Cout, 7, self.wws, dst_offset=ci * 49, exclusive=True)
         red = self._red(Cout, g_c0.device)
         ops.channel_sum(g_c0, red)
         ops.cast_f64_to_f32(red, G(conv1.bias), Cout)

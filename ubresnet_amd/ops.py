@@ -280,7 +280,7 @@ def _tap_arrays_w(taps):
 
 def wgrad(x: torch.Tensor, g: torch.Tensor, taps, dst: torch.Tensor, sm: int, sk: int, Cout_valid: int, Cin_valid: int,
           ws: WgradWorkspace, S: int = 1, iy0: int = 0, ix0: int = 0, xf: Optional[Affine] = None, accumulate: bool = False,
-          dst_offset: int = 0, stream=None):
+          dst_offset: int = 0, stream=None, exclusive: bool = False):
     """dst[co*sm + ci*sk + tapidx] (+)= sum_pixels g[p][co] * xform(x)[p*S + tap][ci]
     taps: [(dy, dx, tapidx into the PyTorch weight layout)]; stream: torch.cuda.Stream to launch on (default: current)"""
     d = L.WgradDesc()
@@ -296,6 +296,7 @@ def wgrad(x: torch.Tensor, g: torch.Tensor, taps, dst: torch.Tensor, sm: int, sk
     dy_a, dx_a, _, _ = _tap_arrays_w(taps)
     C.memmove(d.dy, dy_a, len(taps)); C.memmove(d.dx, dx_a, len(taps))
     d.S, d.iy0, d.ix0 = S, iy0, ix0
+    d.exclusive = 1 if exclusive else 0        # nothing runs beside this launch: fill the GPU
     nsplit, nbytes = C.c_int32(0), C.c_int64(0)
     lib = L.lib()
     L.check(lib.ubr_wgrad_plan(C.byref(d), C.byref(nsplit), C.byref(nbytes)), "wgrad_plan")
