@@ -13,9 +13,13 @@ namespace {
 static int gcd_i(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
 
 // blocks such that blocks*256 is a multiple of CU and the grid covers the work reasonably
-static int pick_blocks(int64_t npix, int CU, int max_blocks = 2048) {
+static int pick_blocks(int64_t npix, int CU, int max_blocks = 2048, int min_iters = 1) {
   const int mult = CU / gcd_i(256, CU);
   int64_t want = (npix * CU + 255) / 256;
+  // reduction passes end with one global fp64 atomic per channel and sum in EVERY block: on the low-resolution layers a thread
+  // per 16-byte unit meant 1024 blocks x 1024 atomics behind four pixels of work each; eight units per thread there
+  // (bn_bwd reduce at 16x16x512: 13 -> 8 us)
+  if (min_iters > 1) want = (want + min_iters - 1) / min_iters;
   if (want > max_blocks) want = max_blocks;
   if (want < 1) want = 1;
   int64_t b = ((want + mult - 1) / mult) * mult;
@@ -704,7 +708,8 @@ static int tail_bwd_common(bool apply, int dtype, int64_t npix, int C, const voi
   k.s2 = scale2; k.t2 = shift2; k.m2 = mean2; k.i2 = invstd2; k.k1_2 = k1_2; k.k2_2 = k2_2;
   k.sb = scale_b; k.mb = mean_b; k.ib = invstd_b; k.k1_b = k1_b; k.k2_b = k2_b;
   k.red2 = red2; k.redb = red_b; k.g_c2 = g_c2; k.g_sc = g_sc; k.g_c2_ps = g_c2_ps; k.g_sc_ps = g_sc_ps;
-  const int blocks = pick_blocks(npix, k.CU, apply ? 2048 : 512);
+  static const int red_iters = [] { const char* e = getenv("UBR_RED_ITERS"); return e ? atoi(e) : 8; }();
+  const int blocks = pick_blocks(npix, k.CU, apply ? 2048 : 512, apply ? 1 : red_iters);
   const size_t lds = apply ? 0 : (size_t)4 * C * sizeof(double);
   if (apply) { UBR_DT_SWITCH(dtype, ubr_launch((tail_bwd_kernel<TT, true>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, k)); }
   else { UBR_DT_SWITCH(dtype, ubr_launch((tail_bwd_kernel<TT, false>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, k)); }
@@ -748,7 +753,8 @@ static int bn_bwd_common(bool apply, int dtype, int64_t npix, int C, const void*
   k.npix = npix; k.C = C; k.CU = C / ubr_cpu(dtype); k.relu = relu;
   k.ga = ga; k.ga2 = ga2; k.c = c; k.ga_ps = ga_ps; k.ga2_ps = ga2_ps; k.c_ps = c_ps;
   k.scale = scale; k.shift = shift; k.mean = mean; k.invstd = invstd; k.k1 = k1; k.k2 = k2; k.red = red; k.gc = gc; k.gc_ps = gc_ps;
-  const int blocks = pick_blocks(npix, k.CU, apply ? 2048 : 1024);
+  static const int red_iters = [] { const char* e = getenv("UBR_RED_ITERS"); return e ? atoi(e) : 8; }();
+  const int blocks = pick_blocks(npix, k.CU, apply ? 2048 : 1024, apply ? 1 : red_iters);
   const size_t lds = apply ? 0 : (size_t)2 * C * sizeof(double);
   if (apply) { UBR_DT_SWITCH(dtype, ubr_launch((bn_bwd_kernel<TT, true>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, k)); }
   else { UBR_DT_SWITCH(dtype, ubr_launch((bn_bwd_kernel<TT, false>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, k)); }
