@@ -1871,7 +1871,9 @@ extern "C" int ubr_pack_weights_batched(int dtype, const ubr_pack_item* items_de
   UBR_CHECK(ubr_dtype_ok(dtype), "ubr_pack_weights_batched: bad dtype");
   UBR_CHECK(items_dev != nullptr && nitems >= 1 && nitems <= 65535, "ubr_pack_weights_batched: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid(48, (unsigned)nitems);
+  // blocks per image: the eight 512x512x9 images are most of the bytes and 48 blocks each left the launch under-parallel
+  // (forward repack 60 -> 40 us at 128; 256 over-subscribes the small images' exits)
+  dim3 grid(128, (unsigned)nitems);
   if (dtype == UBR_F32) ubr_launch(pack_batched_kernel<float>, grid, dim3(256), 0, st, items_dev);
   else if (dtype == UBR_BF16) ubr_launch(pack_batched_kernel<bf16_t>, grid, dim3(256), 0, st, items_dev);
   else ubr_launch(pack_batched_kernel<f16_t>, grid, dim3(256), 0, st, items_dev);
