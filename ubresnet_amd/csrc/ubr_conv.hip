@@ -661,7 +661,7 @@ __global__ __launch_bounds__(256, (ROW7 ? 2 : 3)) void conv_thin_kernel(const Th
       int vo = ok ? relu[u] + goff : -1;
       if (k.dbg & 1) vo = -1;
       hv[u] = __builtin_amdgcn_raw_buffer_load_b128(xr, vo, 0, 0);
-      if constexpr (XF) { if (ok && (unsigned)(hy0 + hyu[u]) < (unsigned)k.H) hok |= 1u << u; }
+      if constexpr (XF) hok |= (unsigned)(ok & ((unsigned)(hy0 + hyu[u]) < (unsigned)k.H)) << u;      // (branch-free: one select per slot)
     }
   };
 
