@@ -239,6 +239,26 @@ int ubr_block_tail_bwd_apply(int dtype, int64_t npix, int C, const void* go, int
                              const float* k1_b, const float* k2_b,
                              void* g_c2, int64_t g_c2_ps, void* g_sc, int64_t g_sc_ps, void* stream);
 
+/* The same three with the final ReLU's mask kept as bits: `relu_mask` holds one byte per pixel and 16-byte channel unit
+ * ([npix][C / channels-per-unit], bit e = "stored output of channel e of the unit is > 0").  The forward writes it beside
+ * `out`; the two backward passes read it instead of `out` -- 1 byte per unit instead of 16, i.e. two of the eight tensor passes
+ * of a block tail's backward (autograd keeps the whole output for threshold_backward; reference models/common_layers.py:56). */
+int ubr_block_tail_fwd_masked(int dtype, int64_t npix, int C, const void* c2, int64_t c2_ps, const float* mean2,
+                              const float* scale2, const float* shift2, const void* sc, int64_t sc_ps, const float* mean_b,
+                              const float* scale_b, const float* shift_b, void* out, int64_t out_ps, uint8_t* relu_mask, void* stream);
+int ubr_block_tail_bwd_reduce_masked(int dtype, int64_t npix, int C, const void* go, int64_t go_ps, const void* go2, int64_t go2_ps,
+                                     const uint8_t* relu_mask, const void* c2, int64_t c2_ps,
+                                     const float* scale2, const float* shift2, const float* mean2, const float* invstd2,
+                                     const void* cb, int64_t cb_ps, const float* mean_b, const float* invstd_b,
+                                     double* red2, double* red_b, void* stream);
+int ubr_block_tail_bwd_apply_masked(int dtype, int64_t npix, int C, const void* go, int64_t go_ps, const void* go2, int64_t go2_ps,
+                                    const uint8_t* relu_mask, const void* c2, int64_t c2_ps,
+                                    const float* scale2, const float* shift2, const float* mean2, const float* invstd2,
+                                    const float* k1_2, const float* k2_2,
+                                    const void* cb, int64_t cb_ps, const float* scale_b, const float* mean_b, const float* invstd_b,
+                                    const float* k1_b, const float* k2_b,
+                                    void* g_c2, int64_t g_c2_ps, void* g_sc, int64_t g_sc_ps, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * nn.MaxPool2d(3, stride, padding=1)  (models/ub_uresnet.py:44 stride 2; ASPP_ResNet.py:222 stride 1)
  * forward reads the (optionally transformed) input, writes the pooled map and optionally the

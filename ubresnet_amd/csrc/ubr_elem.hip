@@ -103,7 +103,8 @@ __device__ __forceinline__ void flush_sums(const float (*acc)[CPU], int c, int C
 // ------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void tail_fwd_kernel(long npix, int CU, const void* c2, long c2_ps, const float* m2p, const float* s2, const float* t2,
-                                                       const void* sc, long sc_ps, const float* mbp, const float* sb, const float* tb, void* out, long out_ps) {
+                                                       const void* sc, long sc_ps, const float* mbp, const float* sb, const float* tb, void* out, long out_ps,
+                                                       uint8_t* relu_mask) {
   constexpr int CPU = ET<T>::CPU;
   UnitIdx<T> ix(CU);
   constexpr int H2 = CPU / 2;
@@ -112,6 +113,8 @@ __global__ __launch_bounds__(256) void tail_fwd_kernel(long npix, int CU, const 
   const bool byp = sb != nullptr;
   if (byp) { ldconst2<CPU>(sb, ix.c, ab); ldconst2<CPU>(tb, ix.c, bb); ldconst2<CPU>(mbp, ix.c, mb); }
   UnitStream<T> C2(c2, npix, c2_ps, ix), SC(sc, npix, sc_ps, ix), OUT(out, npix, out_ps, ix);
+  unsigned moff = (unsigned)ix.p * (unsigned)CU + (unsigned)ix.c;
+  const unsigned mstep = (unsigned)ix.pstep * (unsigned)CU;
   const float zero = 0.f;
 #pragma unroll 2
   for (long p = ix.p; p < npix; p += ix.pstep) {
@@ -128,6 +131,17 @@ __global__ __launch_bounds__(256) void tail_fwd_kernel(long npix, int CU, const 
       o[2 * h] = ubr_vmax(t[0], zero); o[2 * h + 1] = ubr_vmax(t[1], zero);
     }
     OUT.st(o);
+    if (relu_mask != nullptr) {
+      // one bit per channel of this unit: "the STORED output is positive" (after rounding to the storage type, which is what the
+      // backward pass used to test on the tensor itself).  The backward's two passes then read 1 byte per unit instead of 16.
+      float r[CPU];
+      ET<T>::unpack(ET<T>::pack(o), r);
+      unsigned m = 0u;
+#pragma unroll
+      for (int e = 0; e < CPU; ++e) m |= (r[e] > 0.f ? 1u : 0u) << e;
+      relu_mask[moff] = (uint8_t)m;
+      moff += mstep;
+    }
     C2.next(); SC.next(); OUT.next();
   }
 }
@@ -143,6 +157,7 @@ struct TailB {
   const float *sb, *mb, *ib, *k1_b, *k2_b;
   double *red2, *redb;
   void *g_c2, *g_sc; long g_c2_ps, g_sc_ps;
+  const uint8_t* relu_mask;      // optional: bit e of byte [pixel][unit] = (out > 0) for channel e of the unit; replaces the read of `out`
 };
 
 template <typename T, bool APPLY>
@@ -167,6 +182,8 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(const TailB k) {
     for (int e = 0; e < CPU; ++e) acc[qn][e] = 0.f;
   UnitStream<T> GO(k.go, k.npix, k.go_ps, ix), GO2(k.go2, k.npix, k.go2_ps, ix), OUT(k.out, k.npix, k.out_ps, ix),
       C2(k.c2, k.npix, k.c2_ps, ix), CB(k.cb, k.npix, k.cb_ps, ix), GC2(k.g_c2, k.npix, k.g_c2_ps, ix), GSC(k.g_sc, k.npix, k.g_sc_ps, ix);
+  unsigned moff = (unsigned)ix.p * (unsigned)k.CU + (unsigned)ix.c;
+  const unsigned mstep = (unsigned)ix.pstep * (unsigned)k.CU;
 
 #pragma unroll 2
   for (long p = ix.p; p < k.npix; p += ix.pstep) {
@@ -178,7 +195,9 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(const TailB k) {
 #pragma unroll
       for (int e = 0; e < CPU; ++e) g[e] += g2[e];
     }
-    OUT.ld(o);
+    unsigned mbits = 0u;
+    if (k.relu_mask != nullptr) { mbits = k.relu_mask[moff]; moff += mstep; }
+    else OUT.ld(o);
     C2.ld(c2);
     if (byp) CB.ld(cb);
     float r2[CPU], rs[CPU];
@@ -189,7 +208,9 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(const TailB k) {
       const ubr_f2 d2 = ubr_f2{c2[2 * h], c2[2 * h + 1]} - m2[h];
       const ubr_f2 bn = __builtin_elementwise_fma(d2, s2[h], t2[h]);
       const ubr_f2 xh2 = d2 * i2[h];
-      const ubr_f2 gz = {o[2 * h] > 0.f ? g[2 * h] : 0.f, o[2 * h + 1] > 0.f ? g[2 * h + 1] : 0.f};
+      const bool p0 = k.relu_mask != nullptr ? ((mbits >> (2 * h)) & 1u) != 0u : o[2 * h] > 0.f;
+      const bool p1 = k.relu_mask != nullptr ? ((mbits >> (2 * h + 1)) & 1u) != 0u : o[2 * h + 1] > 0.f;
+      const ubr_f2 gz = {p0 ? g[2 * h] : 0.f, p1 ? g[2 * h + 1] : 0.f};
       const ubr_f2 gy2 = {bn[0] > 0.f ? gz[0] : 0.f, bn[1] > 0.f ? gz[1] : 0.f};
       ubr_f2 xhb = {0.f, 0.f};
       if (byp) xhb = (ubr_f2{cb[2 * h], cb[2 * h + 1]} - mb[h]) * ib[h];
@@ -664,9 +685,9 @@ static int check_nhwc(const char* who, int dtype, int64_t npix, int C, const voi
 }
 #define UBR_TRY(x) do { int rc__ = (x); if (rc__ != UBR_OK) return rc__; } while (0)
 
-extern "C" int ubr_block_tail_fwd(int dtype, int64_t npix, int C, const void* c2, int64_t c2_ps, const float* mean2, const float* scale2,
-                                  const float* shift2, const void* sc, int64_t sc_ps, const float* mean_b, const float* scale_b,
-                                  const float* shift_b, void* out, int64_t out_ps, void* stream) {
+static int tail_fwd_common(int dtype, int64_t npix, int C, const void* c2, int64_t c2_ps, const float* mean2, const float* scale2,
+                           const float* shift2, const void* sc, int64_t sc_ps, const float* mean_b, const float* scale_b,
+                           const float* shift_b, void* out, int64_t out_ps, uint8_t* relu_mask, void* stream) {
   UBR_TRY(check_nhwc("ubr_block_tail_fwd(c2)", dtype, npix, C, c2, c2_ps));
   UBR_TRY(check_nhwc("ubr_block_tail_fwd(sc)", dtype, npix, C, sc, sc_ps));
   UBR_TRY(check_nhwc("ubr_block_tail_fwd(out)", dtype, npix, C, out, out_ps));
@@ -674,9 +695,20 @@ extern "C" int ubr_block_tail_fwd(int dtype, int64_t npix, int C, const void* c2
   const int CU = C / ubr_cpu(dtype);
   const int blocks = pick_blocks(npix, CU);
   UBR_DT_SWITCH(dtype, ubr_launch(tail_fwd_kernel<TT>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (long)npix, CU, c2, (long)c2_ps,
-                                          mean2, scale2, shift2, sc, (long)sc_ps, mean_b, scale_b, shift_b, out, (long)out_ps));
+                                          mean2, scale2, shift2, sc, (long)sc_ps, mean_b, scale_b, shift_b, out, (long)out_ps, relu_mask));
   UBR_LAUNCH_CHECK("ubr_block_tail_fwd");
   return UBR_OK;
+}
+extern "C" int ubr_block_tail_fwd(int dtype, int64_t npix, int C, const void* c2, int64_t c2_ps, const float* mean2, const float* scale2,
+                                  const float* shift2, const void* sc, int64_t sc_ps, const float* mean_b, const float* scale_b,
+                                  const float* shift_b, void* out, int64_t out_ps, void* stream) {
+  return tail_fwd_common(dtype, npix, C, c2, c2_ps, mean2, scale2, shift2, sc, sc_ps, mean_b, scale_b, shift_b, out, out_ps, nullptr, stream);
+}
+extern "C" int ubr_block_tail_fwd_masked(int dtype, int64_t npix, int C, const void* c2, int64_t c2_ps, const float* mean2, const float* scale2,
+                                         const float* shift2, const void* sc, int64_t sc_ps, const float* mean_b, const float* scale_b,
+                                         const float* shift_b, void* out, int64_t out_ps, uint8_t* relu_mask, void* stream) {
+  UBR_CHECK(relu_mask != nullptr, "ubr_block_tail_fwd_masked: null mask");
+  return tail_fwd_common(dtype, npix, C, c2, c2_ps, mean2, scale2, shift2, sc, sc_ps, mean_b, scale_b, shift_b, out, out_ps, relu_mask, stream);
 }
 
 static int tail_bwd_common(bool apply, int dtype, int64_t npix, int C, const void* go, int64_t go_ps, const void* go2, int64_t go2_ps,
@@ -685,11 +717,11 @@ static int tail_bwd_common(bool apply, int dtype, int64_t npix, int C, const voi
                            const float* k1_2, const float* k2_2,
                            const void* cb, int64_t cb_ps, const float* scale_b, const float* mean_b, const float* invstd_b,
                            const float* k1_b, const float* k2_b, double* red2, double* red_b,
-                           void* g_c2, int64_t g_c2_ps, void* g_sc, int64_t g_sc_ps, void* stream) {
+                           void* g_c2, int64_t g_c2_ps, void* g_sc, int64_t g_sc_ps, void* stream, const uint8_t* relu_mask = nullptr) {
   const char* who = apply ? "ubr_block_tail_bwd_apply" : "ubr_block_tail_bwd_reduce";
   UBR_TRY(check_nhwc(who, dtype, npix, C, go, go_ps));
   if (go2) UBR_TRY(check_nhwc(who, dtype, npix, C, go2, go2_ps));
-  UBR_TRY(check_nhwc(who, dtype, npix, C, out, out_ps));
+  if (relu_mask == nullptr) UBR_TRY(check_nhwc(who, dtype, npix, C, out, out_ps));
   UBR_TRY(check_nhwc(who, dtype, npix, C, c2, c2_ps));
   if (cb) UBR_TRY(check_nhwc(who, dtype, npix, C, cb, cb_ps));
   UBR_CHECK(scale2 && shift2 && mean2 && invstd2, "%s: null bn2 constants", who);
@@ -708,6 +740,7 @@ static int tail_bwd_common(bool apply, int dtype, int64_t npix, int C, const voi
   k.s2 = scale2; k.t2 = shift2; k.m2 = mean2; k.i2 = invstd2; k.k1_2 = k1_2; k.k2_2 = k2_2;
   k.sb = scale_b; k.mb = mean_b; k.ib = invstd_b; k.k1_b = k1_b; k.k2_b = k2_b;
   k.red2 = red2; k.redb = red_b; k.g_c2 = g_c2; k.g_sc = g_sc; k.g_c2_ps = g_c2_ps; k.g_sc_ps = g_sc_ps;
+  k.relu_mask = relu_mask;
   static const int red_iters = [] { const char* e = getenv("UBR_RED_ITERS"); return e ? atoi(e) : 8; }();
   const int blocks = pick_blocks(npix, k.CU, apply ? 2048 : 512, apply ? 1 : red_iters);
   const size_t lds = apply ? 0 : (size_t)4 * C * sizeof(double);
@@ -736,6 +769,29 @@ extern "C" int ubr_block_tail_bwd_apply(int dtype, int64_t npix, int C, const vo
   return tail_bwd_common(true, dtype, npix, C, go, go_ps, go2, go2_ps, out, out_ps, c2, c2_ps, scale2, shift2, mean2, invstd2,
                          k1_2, k2_2, cb, cb_ps, scale_b, mean_b, invstd_b, k1_b, k2_b, nullptr, nullptr,
                          g_c2, g_c2_ps, g_sc, g_sc_ps, stream);
+}
+// the same two passes reading the forward's ReLU bit mask (ubr_block_tail_fwd_masked) instead of the block output
+extern "C" int ubr_block_tail_bwd_reduce_masked(int dtype, int64_t npix, int C, const void* go, int64_t go_ps, const void* go2, int64_t go2_ps,
+                                                const uint8_t* relu_mask, const void* c2, int64_t c2_ps,
+                                                const float* scale2, const float* shift2, const float* mean2, const float* invstd2,
+                                                const void* cb, int64_t cb_ps, const float* mean_b, const float* invstd_b,
+                                                double* red2, double* red_b, void* stream) {
+  UBR_CHECK(relu_mask != nullptr, "ubr_block_tail_bwd_reduce_masked: null mask");
+  return tail_bwd_common(false, dtype, npix, C, go, go_ps, go2, go2_ps, nullptr, 0, c2, c2_ps, scale2, shift2, mean2, invstd2,
+                         nullptr, nullptr, cb, cb_ps, nullptr, mean_b, invstd_b, nullptr, nullptr, red2, red_b,
+                         nullptr, 0, nullptr, 0, stream, relu_mask);
+}
+extern "C" int ubr_block_tail_bwd_apply_masked(int dtype, int64_t npix, int C, const void* go, int64_t go_ps, const void* go2, int64_t go2_ps,
+                                               const uint8_t* relu_mask, const void* c2, int64_t c2_ps,
+                                               const float* scale2, const float* shift2, const float* mean2, const float* invstd2,
+                                               const float* k1_2, const float* k2_2,
+                                               const void* cb, int64_t cb_ps, const float* scale_b, const float* mean_b, const float* invstd_b,
+                                               const float* k1_b, const float* k2_b,
+                                               void* g_c2, int64_t g_c2_ps, void* g_sc, int64_t g_sc_ps, void* stream) {
+  UBR_CHECK(relu_mask != nullptr, "ubr_block_tail_bwd_apply_masked: null mask");
+  return tail_bwd_common(true, dtype, npix, C, go, go_ps, go2, go2_ps, nullptr, 0, c2, c2_ps, scale2, shift2, mean2, invstd2,
+                         k1_2, k2_2, cb, cb_ps, scale_b, mean_b, invstd_b, k1_b, k2_b, nullptr, nullptr,
+                         g_c2, g_c2_ps, g_sc, g_sc_ps, stream, relu_mask);
 }
 
 static int bn_bwd_common(bool apply, int dtype, int64_t npix, int C, const void* ga, int64_t ga_ps, const void* ga2, int64_t ga2_ps,

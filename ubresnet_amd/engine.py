@@ -33,6 +33,7 @@ DG7 = ops.conv_dgrad_taps_s1(7, 1, 3)
 import os as _os
 # UBR_INFER_FOLD=0: eval forward on the training schedule (BatchNorm applied on load, separate block tails) -- for A/B tests
 _INFER_FOLD = _os.environ.get("UBR_INFER_FOLD", "1") != "0"
+_RELU_MASK = _os.environ.get("UBR_RELU_MASK", "1") != "0"      # block tails keep their final ReLU's mask as bits for the backward
 
 
 def _phase(t, ry, rx):
@@ -298,13 +299,19 @@ class Engine:
             cb = self._new((N, OH, OW, Cout), dtype=dt, device=dev)
             ops.conv(x, self.packed(blk.bypass.weight, dt, "fwd"), cb, T1, Cout, S=S, xf=xf_in, stats=bnb.stats)
             self._finish_bn(bnb, cnt, training)
-            ops.block_tail_fwd(c2, bn2.mean, bn2.scale, bn2.shift, cb, bnb.mean, bnb.scale, bnb.shift, out)
+        # the final ReLU's mask as one byte per 16-byte channel unit: the backward's two passes read it instead of `out`
+        mask = None
+        if self._save and _RELU_MASK:
+            mask = self._new((cnt * (Cout // L.chans_per_unit(dt)),), dtype=torch.uint8, device=dev)
+        if blk.bypass is not None:
+            ops.block_tail_fwd(c2, bn2.mean, bn2.scale, bn2.shift, cb, bnb.mean, bnb.scale, bnb.shift, out, relu_mask=mask)
         else:
-            ops.block_tail_fwd(c2, bn2.mean, bn2.scale, bn2.shift, x, None, None, None, out)
+            ops.block_tail_fwd(c2, bn2.mean, bn2.scale, bn2.shift, x, None, None, None, out, relu_mask=mask)
         if not self._save:
             return None
         rec = Saved()
         rec.blk, rec.x, rec.c1, rec.c2, rec.cb, rec.out, rec.xf_in = blk, x, c1, c2, cb, out, xf_in
+        rec.mask = mask
         return rec
 
     # ------------------------------------------------------------------ backward reduction arena
@@ -430,8 +437,9 @@ class Engine:
         red = self._red((4 if byp else 2) * Cout, dev)
         red2 = red[:2 * Cout * NS]
         redb = red[2 * Cout * NS:] if byp else None
+        mask = getattr(rec, "mask", None)
         ops.block_tail_bwd_reduce(go, go2, out, c2, bn2.scale, bn2.shift, bn2.mean, bn2.invstd,
-                                  cb, bnb.mean if byp else None, bnb.invstd if byp else None, red2, redb)
+                                  cb, bnb.mean if byp else None, bnb.invstd if byp else None, red2, redb, relu_mask=mask)
         k = self._new(4 * Cout, dtype=torch.float32, device=dev)
         ops.bn_bwd_finalize(red2, cnt, Cout, G(blk.bn2.weight), G(blk.bn2.bias), False, k[:Cout], k[Cout:2 * Cout])
         if byp:
@@ -440,7 +448,7 @@ class Engine:
         g_sc = self._new(c2.shape, dtype=dt, device=dev)
         ops.block_tail_bwd_apply(go, go2, out, c2, bn2.scale, bn2.shift, bn2.mean, bn2.invstd, k[:Cout], k[Cout:2 * Cout],
                                  cb, bnb.scale if byp else None, bnb.mean if byp else None, bnb.invstd if byp else None,
-                                 k[2 * Cout:3 * Cout] if byp else None, k[3 * Cout:] if byp else None, g_c2, g_sc)
+                                 k[2 * Cout:3 * Cout] if byp else None, k[3 * Cout:] if byp else None, g_c2, g_sc, relu_mask=mask)
         # conv2: weight grad (input = relu(bn1(c1)) re-formed on load) and data grad
         kk = 9
         self._wg(c1, g_c2, T3, G(blk.conv2.weight), Cout * kk, kk, Cout, Cout, self.wws, xf=self.relu_affine(bn1))

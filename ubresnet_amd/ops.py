@@ -421,30 +421,41 @@ def bn_bwd_apply(ga, ga2, c, scale, shift, mean, invstd, relu, k1, k2, gc):
 # BasicBlock tail
 # ------------------------------------------------------------------------------------------
 @_timed("block_tail_fwd")
-def block_tail_fwd(c2, mean2, scale2, shift2, sc, mean_b, scale_b, shift_b, out):
-    L.check(L.lib().ubr_block_tail_fwd(L.dtype_id(c2.dtype), _npix(c2), c2.shape[3], c2.data_ptr(), _ps(c2), mean2.data_ptr(),
-                                       scale2.data_ptr(), shift2.data_ptr(), sc.data_ptr(), _ps(sc), L.ptr(mean_b), L.ptr(scale_b),
-                                       L.ptr(shift_b), out.data_ptr(), _ps(out), L.stream_ptr()), "block_tail_fwd")
+def block_tail_fwd(c2, mean2, scale2, shift2, sc, mean_b, scale_b, shift_b, out, relu_mask=None):
+    """relu_mask: uint8 [npix * C / channels-per-unit], written with one bit per channel (stored output > 0) for the backward"""
+    a = (L.dtype_id(c2.dtype), _npix(c2), c2.shape[3], c2.data_ptr(), _ps(c2), mean2.data_ptr(),
+         scale2.data_ptr(), shift2.data_ptr(), sc.data_ptr(), _ps(sc), L.ptr(mean_b), L.ptr(scale_b),
+         L.ptr(shift_b), out.data_ptr(), _ps(out))
+    if relu_mask is None:
+        L.check(L.lib().ubr_block_tail_fwd(*a, L.stream_ptr()), "block_tail_fwd")
+    else:
+        L.check(L.lib().ubr_block_tail_fwd_masked(*a, relu_mask.data_ptr(), L.stream_ptr()), "block_tail_fwd_masked")
 
 
 @_timed("block_tail_bwd_reduce")
-def block_tail_bwd_reduce(go, go2, out, c2, scale2, shift2, mean2, invstd2, cb, mean_b, invstd_b, red2, red_b):
-    L.check(L.lib().ubr_block_tail_bwd_reduce(
-        L.dtype_id(c2.dtype), _npix(c2), c2.shape[3], go.data_ptr(), _ps(go), L.ptr(go2), _ps(go2) if go2 is not None else 0,
-        out.data_ptr(), _ps(out), c2.data_ptr(), _ps(c2), scale2.data_ptr(), shift2.data_ptr(), mean2.data_ptr(), invstd2.data_ptr(),
-        L.ptr(cb), _ps(cb) if cb is not None else 0, L.ptr(mean_b), L.ptr(invstd_b), red2.data_ptr(), L.ptr(red_b),
-        L.stream_ptr()), "block_tail_bwd_reduce")
+def block_tail_bwd_reduce(go, go2, out, c2, scale2, shift2, mean2, invstd2, cb, mean_b, invstd_b, red2, red_b, relu_mask=None):
+    """relu_mask (from block_tail_fwd): read instead of `out`"""
+    head = (L.dtype_id(c2.dtype), _npix(c2), c2.shape[3], go.data_ptr(), _ps(go), L.ptr(go2), _ps(go2) if go2 is not None else 0)
+    rest = (c2.data_ptr(), _ps(c2), scale2.data_ptr(), shift2.data_ptr(), mean2.data_ptr(), invstd2.data_ptr(),
+            L.ptr(cb), _ps(cb) if cb is not None else 0, L.ptr(mean_b), L.ptr(invstd_b), red2.data_ptr(), L.ptr(red_b), L.stream_ptr())
+    if relu_mask is None:
+        L.check(L.lib().ubr_block_tail_bwd_reduce(*head, out.data_ptr(), _ps(out), *rest), "block_tail_bwd_reduce")
+    else:
+        L.check(L.lib().ubr_block_tail_bwd_reduce_masked(*head, relu_mask.data_ptr(), *rest), "block_tail_bwd_reduce_masked")
 
 
 @_timed("block_tail_bwd_apply")
 def block_tail_bwd_apply(go, go2, out, c2, scale2, shift2, mean2, invstd2, k1_2, k2_2,
-                         cb, scale_b, mean_b, invstd_b, k1_b, k2_b, g_c2, g_sc):
-    L.check(L.lib().ubr_block_tail_bwd_apply(
-        L.dtype_id(c2.dtype), _npix(c2), c2.shape[3], go.data_ptr(), _ps(go), L.ptr(go2), _ps(go2) if go2 is not None else 0,
-        out.data_ptr(), _ps(out), c2.data_ptr(), _ps(c2), scale2.data_ptr(), shift2.data_ptr(), mean2.data_ptr(), invstd2.data_ptr(),
-        k1_2.data_ptr(), k2_2.data_ptr(),
-        L.ptr(cb), _ps(cb) if cb is not None else 0, L.ptr(scale_b), L.ptr(mean_b), L.ptr(invstd_b), L.ptr(k1_b), L.ptr(k2_b),
-        g_c2.data_ptr(), _ps(g_c2), g_sc.data_ptr(), _ps(g_sc), L.stream_ptr()), "block_tail_bwd_apply")
+                         cb, scale_b, mean_b, invstd_b, k1_b, k2_b, g_c2, g_sc, relu_mask=None):
+    head = (L.dtype_id(c2.dtype), _npix(c2), c2.shape[3], go.data_ptr(), _ps(go), L.ptr(go2), _ps(go2) if go2 is not None else 0)
+    rest = (c2.data_ptr(), _ps(c2), scale2.data_ptr(), shift2.data_ptr(), mean2.data_ptr(), invstd2.data_ptr(),
+            k1_2.data_ptr(), k2_2.data_ptr(),
+            L.ptr(cb), _ps(cb) if cb is not None else 0, L.ptr(scale_b), L.ptr(mean_b), L.ptr(invstd_b), L.ptr(k1_b), L.ptr(k2_b),
+            g_c2.data_ptr(), _ps(g_c2), g_sc.data_ptr(), _ps(g_sc), L.stream_ptr())
+    if relu_mask is None:
+        L.check(L.lib().ubr_block_tail_bwd_apply(*head, out.data_ptr(), _ps(out), *rest), "block_tail_bwd_apply")
+    else:
+        L.check(L.lib().ubr_block_tail_bwd_apply_masked(*head, relu_mask.data_ptr(), *rest), "block_tail_bwd_apply_masked")
 
 
 # ------------------------------------------------------------------------------------------
