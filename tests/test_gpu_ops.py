@@ -374,6 +374,29 @@ def test_block_tail(dt, bypass, C, N, H, W):
     if bypass:
         close(dgb.cpu(), gbr.grad, t, "dgamma_b")
         close(dbb.cpu(), bbr.grad, t, "dbeta_b")
+    # the masked form (what the executor runs): the forward also writes one bit per channel "stored output > 0", the backward
+    # passes read those bytes instead of `out` -- bitwise the same results
+    cpu_ = 4 if dt == torch.float32 else 8
+    mask = torch.full((N * H * W * (C // cpu_) + 3,), 0xAA, dtype=torch.uint8, device=DEV)
+    out_m = torch.empty_like(outd)
+    ops.block_tail_fwd(c2d, d(m2), d(s2), d(t2), scd, d(mb) if bypass else None, d(sb) if bypass else None, d(tb) if bypass else None, out_m,
+                       relu_mask=mask)
+    torch.cuda.synchronize()
+    assert torch.equal(out_m, outd)
+    assert (mask[-3:] == 0xAA).all(), "mask written beyond npix * units"
+    bits = (mask[:-3].view(N, H, W, C // cpu_, 1) >> torch.arange(cpu_, device=DEV, dtype=torch.uint8)) & 1
+    assert torch.equal(bits.reshape(N, H, W, C).bool(), outd.float() > 0)
+    red2m, redbm = statbuf(2 * C), statbuf(2 * C)
+    junk = torch.full_like(outd, float("nan"))          # `out` must not be read in the masked form
+    ops.block_tail_bwd_reduce(go1d, go2d, junk, c2d, d(s2), d(t2), d(m2), d(i2), scd if bypass else None,
+                              d(mb) if bypass else None, d(ib) if bypass else None, red2m, redbm if bypass else None, relu_mask=mask)
+    g_c2m, g_scm = torch.empty_like(g_c2), torch.empty_like(g_sc)
+    ops.block_tail_bwd_apply(go1d, go2d, junk, c2d, d(s2), d(t2), d(m2), d(i2), k[:C], k[C:2 * C],
+                             scd if bypass else None, d(sb) if bypass else None, d(mb) if bypass else None, d(ib) if bypass else None,
+                             k[2 * C:3 * C] if bypass else None, k[3 * C:] if bypass else None, g_c2m, g_scm, relu_mask=mask)
+    torch.cuda.synchronize()
+    assert torch.equal(g_c2m, g_c2) and torch.equal(g_scm, g_sc)
+    assert torch.allclose(slotsum(red2m, 2 * C), slotsum(red2, 2 * C), rtol=1e-12, atol=1e-9)
 
 
 @pytest.mark.parametrize("dt", DTS)
