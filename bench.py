@@ -323,7 +323,15 @@ def main():
     else:   # ASPP ip16 @3x512x832: 442.0 M elements train-forward, 169.77 GF forward
         per_img = 3 * 442.0e6 * esz
         flop_img = 3 * 169.77e9
-    res["step_model"] = {"algorithmic_bytes_per_image": per_img, "achieved_GBs_per_gpu": per_img * a.batch * a.steps / el / 1e9,
+    pmc_step = None
+    try:   # whole-step HBM bytes from the committed rocprofv3 --pmc collection of this command (tools/pmc_traffic.py), if it matches
+        pm = json.load(open(os.path.join(REPO, "profiles", "r02_pmc_traffic.json")))
+        if pm.get("dtype") == a.dtype and pm.get("batch") == a.batch and a.model == "uresnet" and a.inplanes == 16 and a.size == 512:
+            pmc_step = pm.get("hbm_bytes_per_step") or sum(v["launches_profiled"] / 4.0 * v["hbm_bytes_per_launch"] for v in pm["kernels"].values())
+    except Exception:
+        pass
+    res["step_model"] = {"pmc_hbm_bytes_per_step": pmc_step, "pmc_over_algorithmic": (pmc_step / (per_img * a.batch)) if pmc_step else None,
+                         "algorithmic_bytes_per_image": per_img, "achieved_GBs_per_gpu": per_img * a.batch * a.steps / el / 1e9,
                          "frac_of_hbm_peak": per_img * a.batch * a.steps / el / 1e9 / HBM_PEAK_GBS,
                          "achieved_TFLOPs_per_gpu": flop_img * a.batch * a.steps / el / 1e12}
 

@@ -56,7 +56,9 @@ def main():
         w = wt.get(k, 0.0) / max(wc.get(k, 1), 1)
         kernels[k] = {"launches_profiled": n, "fetch_size_kb_per_launch": f, "write_size_kb_per_launch": w,
                       "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0}
-    doc = {"dtype": "bf16", "batch": 16,
+    steps = 4          # bench.py --steps 3 --warmup 1
+    per_step = sum(v["launches_profiled"] / steps * v["hbm_bytes_per_launch"] for v in kernels.values())
+    doc = {"dtype": "bf16", "batch": 16, "steps_profiled": steps, "hbm_bytes_per_step": per_step,
            "command": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-breakdown",
            "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE counts 128-B requests at 64 B)",
            "kernels": kernels}
