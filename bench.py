@@ -2,7 +2,8 @@
 """Headline benchmark: images/sec of one full U-ResNet train step (forward + PixelWiseNLLLoss +
 backward + Adam) on synthetic 512x512 LArTPC crops, data-parallel over N MI355X.
 
-    python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 8 --steps 20 --warmup 5          (starts its own 8 ranks, see _self_launch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -34,8 +35,8 @@ MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # dense peaks
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200, help="timed steps (default: a timed region of ~2.5 s)")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=16, help="images per GPU")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--inplanes", type=int, default=16)
@@ -47,7 +48,102 @@ def parse():
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--no-infer", action="store_true", help="skip the whole-view inference leg (BASELINE configs[4])")
     ap.add_argument("--breakdown-file", default="")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the ASPP_ResNet (configs[3]) and inplanes=32 (wlarcv2 variant) legs of the N=1 line")
+    ap.add_argument("--extra-steps", type=int, default=5, help="timed steps of each extra leg")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CPU rehearsal of the launch path (gloo, no kernels): ranks, gradient exchange and the JSON line; `value` is not a measurement")
     return ap.parse_args()
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _self_launch(a):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start the N ranks ourselves as children of a
+    torch.distributed.run subprocess (one process per GPU, rendezvous on 127.0.0.1) BEFORE this process has made any GPU
+    call, pass rank 0's JSON line through, exit with the children's status.  (Nothing here touches HIP: the parent only
+    imported torch; a process that has initialised the GPU must not exec another program on this pool.)"""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            sys.stderr.write(ln + "\n")
+    if line is not None:
+        print(line, flush=True)
+    if r.returncode != 0 or line is None:
+        raise SystemExit(r.returncode or 1)
+
+
+def dry_run(a):
+    """CPU rehearsal of the N-rank job (tests/test_cpu_host.py): gloo process group, replicated model, bucketed gradient
+    exchange through ubresnet_amd.dist.GradAllReducer fed in completion order, barrier + max-over-ranks timing and rank 0's
+    JSON line -- everything of bench.py's launch path except the HIP kernels (there is no CPU compute path)."""
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if "RANK" in os.environ:
+        dist.init_process_group("gloo")
+    from ubresnet_amd.dist import GradAllReducer, shard_range
+    from ubresnet_amd.models.ub_uresnet import UResNet
+    torch.manual_seed(1234 + rank)             # replicas start DIFFERENT: the reducer's broadcast makes them equal
+    model = UResNet(num_classes=3, input_channels=1, inplanes=a.inplanes)
+    reducer = GradAllReducer(model, bucket_bytes=8 << 20) if dist.is_initialized() else None
+    n = sum(p.numel() for p in model.parameters())
+    gb = a.batch * world
+    lo, hi = shard_range(gb, rank, world)
+
+    def step(i):
+        flat = torch.full((n,), float(rank + 1 + i))
+        if reducer is not None:
+            for c0 in range(0, n, 3000000):
+                model._grad_ready_hook(flat, c0, min(n, c0 + 3000000))
+            reducer.finish()
+        return flat
+
+    for i in range(a.warmup):
+        step(i)
+    if dist.is_initialized():
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        flat = step(i)
+    if dist.is_initialized():
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if dist.is_initialized():
+        t = torch.tensor([el], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    want = sum(r + 1 + a.steps - 1 for r in range(world)) / world
+    ok = bool(torch.allclose(flat, torch.full_like(flat, want)))
+    digest = torch.cat([p.detach().reshape(-1)[:4] for p in model.parameters()]).double().sum().reshape(1)
+    if dist.is_initialized():
+        ds = [torch.zeros_like(digest) for _ in range(world)]
+        dist.all_gather(ds, digest)
+        ok = ok and all(torch.equal(ds[0], d) for d in ds)
+    if rank == 0:
+        print(json.dumps({"metric": "images/sec, 512x512 U-ResNet train step (fwd+loss+bwd+Adam)", "value": gb * a.steps / el, "unit": "images/sec",
+                          "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * el / a.steps, "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic", "dry_run": True,
+                          "config": {"workload": "DRY RUN on CPU (gloo): launch path and gradient exchange only, no kernels; value is not a measurement",
+                                     "parallelism": "dp%d" % world, "global_batch": gb, "shard_of_rank0": [lo, hi]},
+                          "exchange_ok": ok}), flush=True)
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(3)
 
 
 def host_cores():
@@ -91,8 +187,8 @@ def _trained_iou(size, inplanes, steps=200):
         loss.backward()
         opt.step()
         if i == 0:
-            first = float(loss)
-    last = float(loss)
+            first = float(loss.detach())
+    last = float(loss.detach())
     sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
     xh, labh, _ = synthetic.make_batch(2, size, size, 9000)
     xt = torch.from_numpy(xh)
@@ -229,51 +325,85 @@ def infer_leg(events=6, warmup=2):
                          "algorithmic_bytes_per_tile": gb_tile, "scope": "whole event (crop + graph replay + stitch)"}}
 
 
-def main():
-    a = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ
-    if world > 1 or launched:
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    elif a.gpus != 1:
-        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
-    dev = torch.device("cuda", local if world > 1 else 0)
-    torch.cuda.set_device(dev)
+def _pmc_file():
+    """whole-step / per-kernel HBM bytes from the committed rocprofv3 --pmc collection (tools/pmc_traffic.py), only while it
+    still describes the kernels being run: the file carries a hash of ubresnet_amd/csrc/ taken when it was collected"""
+    try:
+        from ubresnet_amd.build import source_hash
+        for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+            f = os.path.join(REPO, "profiles", name)
+            if os.path.exists(f):
+                pm = json.load(open(f))
+                if pm.get("csrc_sha256") == source_hash():
+                    return pm
+                return None
+    except Exception:
+        pass
+    return None
 
+
+def _rooflines(prof, dtype, pmc=None):
+    """dominant kernel symbol (as rocprofv3 --kernel-trace --stats names it) of a per-launch breakdown taken with HIP events
+    on the launch streams, plus the same figures for the next kernels by time"""
+    bysym = prof.summary(by="kernel")
+    tot = sum(v[1] for v in bysym.values())
+    # (launches the operator wrappers do not label -- BatchNorm finalize kernels, memsets -- are one pseudo entry: it
+    # counts in the total, it is not a kernel symbol)
+    real = {k: v for k, v in bysym.items() if not k.startswith("launches outside")}
+    peak_tf = MFMA_PEAK_TFLOPS[dtype]
+    ridge = peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9)
+
+    def entry(sy, c_, t_, b_, fl_):
+        mf = fl_ / max(b_, 1) > ridge
+        ach = fl_ / t_ / 1e12 if mf else b_ / t_ / 1e9
+        pk = peak_tf if mf else HBM_PEAK_GBS
+        return {"kernel": sy, "launches_per_step": c_, "avg_launch_us": 1e6 * t_ / c_, "bound": "mfma" if mf else "hbm",
+                "achieved": ach, "peak": pk, "unit": "TFLOP/s" if mf else "GB/s", "frac": ach / pk, "share_of_gpu_time": t_ / tot}
+
+    sym, (cnt, tsum, nbytes, flops) = max(real.items(), key=lambda kv: kv[1][1])
+    top = entry(sym, cnt, tsum, nbytes, flops)
+    traffic = None
+    if pmc is not None and sym in pmc.get("kernels", {}):
+        traffic = pmc["kernels"][sym]["hbm_bytes_per_launch"]
+    roof = {"bound": top["bound"], "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"], "frac": top["frac"], "traffic": traffic,
+            "kernel": sym, "launches_per_step": cnt, "avg_launch_us": 1e6 * tsum / cnt, "algorithmic_bytes_per_launch": nbytes / cnt,
+            "algorithmic_flop_per_launch": flops / cnt, "arithmetic_intensity": flops / max(nbytes, 1), "share_of_gpu_time": tsum / tot}
+    tops = [entry(sy, *v) for sy, v in sorted(real.items(), key=lambda kv: -kv[1][1])[:8]]
+    return roof, tops, tot, bysym
+
+
+def train_leg(kind, inplanes, batch, size, dtype, steps, warmup, optimizer, world, rank, dev, breakdown, breakdown_file=""):
+    """K timed train steps (forward + PixelWiseNLLLoss + zero_grad + backward + [gradient all-reduce] + Adam) of one model
+    configuration, inputs resident in HBM; returns the fields of a bench line for it (rank 0; other ranks get the timing)."""
     from ubresnet_amd import ops, synthetic
     from ubresnet_amd.dist import GradAllReducer, shard_range
-    from ubresnet_amd.models.ub_uresnet import UResNet
     from ubresnet_amd.training.pixelwise_nllloss import PixelWiseNLLLoss
-
-    dt = {"bf16": torch.bfloat16, "f32": torch.float32, "f16": torch.float16}[a.dtype]
+    dt = {"bf16": torch.bfloat16, "f32": torch.float32, "f16": torch.float16}[dtype]
     torch.manual_seed(1234)                     # identical initial weights on every rank (DP replicas)
-    if a.model == "aspp":
+    if kind == "aspp":
         from ubresnet_amd.models.ASPP_ResNet import ASPP_ResNet
         model = ASPP_ResNet(num_classes=3, in_channels=3, inplanes=16, showsizes=False).to(dev)
-        planes, H, W = 3, 512, 832
+        planes, H, W, inplanes = 3, 512, 832, 16
     else:
-        model = UResNet(num_classes=3, input_channels=1, inplanes=a.inplanes).to(dev)
-        planes, H, W = 1, a.size, a.size
+        from ubresnet_amd.models.ub_uresnet import UResNet
+        model = UResNet(num_classes=3, input_channels=1, inplanes=inplanes).to(dev)
+        planes, H, W = 1, size, size
     model.compute_dtype = dt
     model.train()
     crit = PixelWiseNLLLoss()
-    params = [p for p in model.parameters()]
     # reference: Adam(lr 1e-5, weight_decay 1e-4), wlarcv2.py:155-157.  Default: this package's flat Adam (same arithmetic, one
     # launch over the flat parameter / gradient buffers); --optimizer torch uses torch.optim.Adam(fused=True).
-    if a.optimizer == "flat":
+    if optimizer == "flat":
         from ubresnet_amd.optim import FlatAdam
         opt = FlatAdam(model, lr=1e-5, weight_decay=1e-4)
     else:
-        opt = torch.optim.Adam(params, lr=1e-5, weight_decay=1e-4, fused=True)
+        opt = torch.optim.Adam(list(model.parameters()), lr=1e-5, weight_decay=1e-4, fused=True)
     reducer = GradAllReducer(model, bucket_bytes=int(float(os.environ.get("UBR_BUCKET_MB", "8")) * (1 << 20))) if dist.is_initialized() else None
 
     # synthetic crops: rank r holds images [r*b, (r+1)*b) of the global batch, resident in HBM
-    gb = a.batch * world
+    gb = batch * world
     lo, hi = shard_range(gb, rank, world)
-    x, lab, wgt = synthetic.make_batch(a.batch, H, W, seed0=1000 + lo * planes, planes=planes)
+    x, lab, wgt = synthetic.make_batch(batch, H, W, seed0=1000 + lo * planes, planes=planes)
     x, lab, wgt = torch.from_numpy(x).to(dev), torch.from_numpy(lab).to(dev), torch.from_numpy(wgt).to(dev)
 
     def step():
@@ -286,13 +416,13 @@ def main():
         opt.step()
         return loss
 
-    for _ in range(a.warmup):
+    for _ in range(warmup):
         step()
     if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(steps):
         loss = step()
     torch.cuda.synchronize()
     if dist.is_initialized():
@@ -302,41 +432,45 @@ def main():
         t = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
-    lossv = float(loss.item())
+    lossv = float(loss.detach().item())
 
+    name = "ASPP_ResNet" if kind == "aspp" else "ub_uresnet"
     res = {
-        "metric": ("images/sec, 512x512 U-ResNet train step (fwd+loss+bwd+Adam)" if a.model == "uresnet"
+        "metric": ("images/sec, 512x512 U-ResNet train step (fwd+loss+bwd+Adam)" if kind == "uresnet"
                    else "images/sec, 3x512x832 ASPP-ResNet train step (fwd+loss+bwd+Adam)"),
-        "value": gb * a.steps / el, "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": 1e3 * el / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": a.dtype, "data": "synthetic",
+        "value": gb * steps / el, "unit": "images/sec", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": 1e3 * el / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": dtype, "data": "synthetic",
         "config": {"workload": "%s 3-class ip%d %s, batch %d per GPU (global %d), %dx%dx%d synthetic LArTPC crops, Adam(1e-5, wd 1e-4)"
-                               % ("ub_uresnet" if a.model == "uresnet" else "ASPP_ResNet", a.inplanes, a.dtype, a.batch, gb, H, W, planes),
+                               % (name, inplanes, dtype, batch, gb, H, W, planes),
                    "parallelism": "dp%d" % world, "global_batch": gb,
-                   "optimizer": "ubresnet_amd.optim.FlatAdam" if a.optimizer == "flat" else "torch.optim.Adam(fused=True)"},
+                   "optimizer": "ubresnet_amd.optim.FlatAdam" if optimizer == "flat" else "torch.optim.Adam(fused=True)"},
         "final_loss": lossv,
     }
-    esz = 4 if a.dtype == "f32" else 2
-    if a.model == "uresnet":
-        per_img = MODEL_BYTES_PER_IMG_BF16 * (esz / 2.0) * (a.size * a.size / 262144.0) * (a.inplanes / 16.0)
-        flop_img = MODEL_FLOP_PER_IMG * (a.size * a.size / 262144.0)
-    else:   # SURVEY.md section 8d: ASPP ip16 @3x512x832: 442.0 M elements train-forward, 169.77 GF forward
-        per_img = 3 * 442.0e6 * esz
-        flop_img = 3 * 169.77e9
+    esz = 4 if dtype == "f32" else 2
+    if kind == "uresnet":   # SURVEY.md section 8d; ip32: 488.9 M elements train-forward, 248.75 GF forward
+        if inplanes == 32:
+            per_img, flop_img = 3 * 488.9e6 * esz * (size * size / 262144.0), 3 * 248.75e9 * (size * size / 262144.0)
+        else:
+            per_img = MODEL_BYTES_PER_IMG_BF16 * (esz / 2.0) * (size * size / 262144.0) * (inplanes / 16.0)
+            flop_img = MODEL_FLOP_PER_IMG * (size * size / 262144.0) * (inplanes / 16.0) ** 2
+    else:   # ASPP ip16 @3x512x832: 442.0 M elements train-forward, 169.77 GF forward
+        per_img, flop_img = 3 * 442.0e6 * esz, 3 * 169.77e9
+    headline = kind == "uresnet" and inplanes == 16 and size == 512
+    pmc = _pmc_file() if headline else None
+    if pmc is not None and not (pmc.get("dtype") == dtype and pmc.get("batch") == batch):
+        pmc = None
     pmc_step = None
-    try:   # whole-step HBM bytes from the committed rocprofv3 --pmc collection of this command (tools/pmc_traffic.py), if it matches
-        pm = json.load(open(os.path.join(REPO, "profiles", "r02_pmc_traffic.json")))
-        if pm.get("dtype") == a.dtype and pm.get("batch") == a.batch and a.model == "uresnet" and a.inplanes == 16 and a.size == 512:
-            pmc_step = pm.get("hbm_bytes_per_step") or sum(v["launches_profiled"] / 4.0 * v["hbm_bytes_per_launch"] for v in pm["kernels"].values())
-    except Exception:
-        pass
-    res["step_model"] = {"pmc_hbm_bytes_per_step": pmc_step, "pmc_over_algorithmic": (pmc_step / (per_img * a.batch)) if pmc_step else None,
-                         "algorithmic_bytes_per_image": per_img, "achieved_GBs_per_gpu": per_img * a.batch * a.steps / el / 1e9,
-                         "frac_of_hbm_peak": per_img * a.batch * a.steps / el / 1e9 / HBM_PEAK_GBS,
-                         "achieved_TFLOPs_per_gpu": flop_img * a.batch * a.steps / el / 1e12}
+    if pmc is not None:
+        pmc_step = pmc.get("hbm_bytes_per_step") or sum(v["launches_profiled"] / 4.0 * v["hbm_bytes_per_launch"] for v in pmc["kernels"].values())
+    res["step_model"] = {"pmc_hbm_bytes_per_step": pmc_step, "pmc_over_algorithmic": (pmc_step / (per_img * batch)) if pmc_step else None,
+                         "algorithmic_bytes_per_image": per_img, "achieved_GBs_per_gpu": per_img * batch * steps / el / 1e9,
+                         "frac_of_hbm_peak": per_img * batch * steps / el / 1e9 / HBM_PEAK_GBS,
+                         "achieved_TFLOPs_per_gpu": flop_img * batch * steps / el / 1e12,
+                         "frac_of_mfma_peak": flop_img * batch * steps / el / 1e12 / MFMA_PEAK_TFLOPS[dtype]}
 
-    # ---- per-launch breakdown of one more step (HIP events on the launch stream) -> roofline of the dominant kernel
-    if not a.no_breakdown:
+    # ---- per-launch breakdown of one more step (HIP events on the launch streams) -> roofline of the dominant kernel
+    if breakdown:
         # Launch tapes: the taped launches are timed INSIDE a replay (events around every launch on its own stream, same two-stream
         # overlap as the timed steps and as the rocprofv3 run of this command); the few launches issued from Python (head,
         # loss, stem expansion, optimizer) are timed by the operator wrappers as before.
@@ -348,73 +482,70 @@ def main():
         ops._prof = None
         _plan.TIMED = None
         torch.cuda.synchronize()
-    if rank == 0 and not a.no_breakdown:
-        # dominant KERNEL SYMBOL (as rocprofv3 --kernel-trace --stats names it): launches, average duration and the
-        # algorithmic bytes/flops it moved, all from HIP events recorded on the launch stream in this run
-        bysym = prof.summary(by="kernel")
-        tot = sum(v[1] for v in bysym.values())
-        # (launches the operator wrappers do not label -- BatchNorm finalize kernels, memsets -- are one pseudo entry: it
-        # counts in the total, it is not a kernel symbol)
-        real = {k: v for k, v in bysym.items() if not k.startswith("launches outside")}
-        sym, (cnt, tsum, nbytes, flops) = max(real.items(), key=lambda kv: kv[1][1])
-        ai = flops / max(nbytes, 1)
-        peak_tf = MFMA_PEAK_TFLOPS[a.dtype]
-        mfma_bound = ai > peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9)
-        traffic = None
-        try:   # HBM bytes per launch from a committed rocprofv3 --pmc collection of this command (profiles/), if present
-            pm = json.load(open(os.path.join(REPO, "profiles", "r02_pmc_traffic.json")))
-            if pm.get("dtype") == a.dtype and pm.get("batch") == a.batch and sym in pm.get("kernels", {}):
-                traffic = pm["kernels"][sym]["hbm_bytes_per_launch"]
-        except Exception:
-            pass
-        if mfma_bound:
-            ach = flops / tsum / 1e12
-            res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak_tf, "unit": "TFLOP/s", "frac": ach / peak_tf, "traffic": traffic}
-        else:
-            ach = nbytes / tsum / 1e9
-            res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic}
-        res["roofline"].update({"kernel": sym, "launches_per_step": cnt, "avg_launch_us": 1e6 * tsum / cnt,
-                                "algorithmic_bytes_per_launch": nbytes / cnt, "algorithmic_flop_per_launch": flops / cnt,
-                                "arithmetic_intensity": ai, "share_of_gpu_time": tsum / tot})
-        # the same figures for the next kernels by time, and for the layer round 1's review named (the full-resolution
-        # 16->16 3x3 convolutions: 268 MB of algorithmic traffic per launch)
-        ridge = peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9)
-        tops = []
-        for sy, (c_, t_, b_, fl_) in sorted(real.items(), key=lambda kv: -kv[1][1])[:8]:
-            mf = fl_ / max(b_, 1) > ridge
-            ach_ = fl_ / t_ / 1e12 if mf else b_ / t_ / 1e9
-            pk_ = peak_tf if mf else HBM_PEAK_GBS
-            tops.append({"kernel": sy, "launches_per_step": c_, "avg_launch_us": 1e6 * t_ / c_, "bound": "mfma" if mf else "hbm",
-                         "achieved": ach_, "unit": "TFLOP/s" if mf else "GB/s", "frac": ach_ / pk_, "share_of_gpu_time": t_ / tot})
-        res["roofline_top_kernels"] = tops
-        if a.model == "uresnet":
-            want = "%dx%dx%dx%d" % (a.batch, a.size, a.size, a.inplanes)
-            agg = [0, 0.0, 0]
-            for (nm, sg), (c_, t_, b_, fl_) in prof.summary(by="shape").items():
-                parts = sg.split(" ")
-                if nm == "conv" and "taps9" in parts and parts[0] == want and parts[2] == want and "S2" not in parts:
-                    agg[0] += c_; agg[1] += t_; agg[2] += b_
-            if agg[0]:
-                res["roofline_fullres_3x3_conv"] = {"layer": "3x3 %d->%d at %dx%d, batch %d (forward and data-gradient launches)" % (a.inplanes, a.inplanes, a.size, a.size, a.batch),
-                                                    "launches_per_step": agg[0], "avg_launch_us": 1e6 * agg[1] / agg[0], "bound": "hbm", "achieved": agg[2] / agg[1] / 1e9,
-                                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": agg[2] / agg[1] / 1e9 / HBM_PEAK_GBS,
-                                                    "algorithmic_bytes_per_launch": agg[2] / agg[0]}
-        res["kernel_time_ms_per_step"] = 1e3 * tot
-        if a.breakdown_file:
-            with open(a.breakdown_file, "w") as f:
-                f.write("== by kernel symbol ==\n%-64s %5s %10s %9s %9s %9s %7s\n" % ("kernel", "n", "total_ms", "avg_us", "GB/s", "TFLOP/s", "share"))
-                for sy, (c_, t_, b_, fl_) in sorted(bysym.items(), key=lambda kv: -kv[1][1]):
-                    f.write("%-64s %5d %10.3f %9.1f %9.1f %9.1f %6.1f%%\n" % (sy, c_, 1e3 * t_, 1e6 * t_ / c_, b_ / max(t_, 1e-12) / 1e9, fl_ / max(t_, 1e-12) / 1e12, 100 * t_ / tot))
-                f.write("\n== by (op, shape) ==\n%-14s %-62s %5s %10s %9s %9s %7s\n" % ("op", "shape", "n", "total_ms", "GB/s", "TFLOP/s", "share"))
-                for (nm, sg), (c_, t_, b_, fl_) in sorted(prof.summary(by="shape").items(), key=lambda kv: -kv[1][1]):
-                    f.write("%-14s %-62s %5d %10.3f %9.1f %9.1f %6.1f%%\n" % (nm, sg, c_, 1e3 * t_, b_ / max(t_, 1e-12) / 1e9, fl_ / max(t_, 1e-12) / 1e12, 100 * t_ / tot))
-    if rank == 0 and world == 1 and not a.no_infer:
-        del model, opt
+        if rank == 0:
+            roof, tops, tot, bysym = _rooflines(prof, dtype, pmc)
+            res["roofline"] = roof
+            res["roofline_top_kernels"] = tops
+            if headline:
+                # the layer round 1's review named (the full-resolution 16->16 3x3 convolutions: 268 MB of algorithmic traffic per launch)
+                want = "%dx%dx%dx%d" % (batch, size, size, inplanes)
+                agg = [0, 0.0, 0]
+                for (nm, sg), (c_, t_, b_, fl_) in prof.summary(by="shape").items():
+                    parts = sg.split(" ")
+                    if nm == "conv" and "taps9" in parts and parts[0] == want and parts[2] == want and "S2" not in parts:
+                        agg[0] += c_; agg[1] += t_; agg[2] += b_
+                if agg[0]:
+                    res["roofline_fullres_3x3_conv"] = {"layer": "3x3 %d->%d at %dx%d, batch %d (forward and data-gradient launches)" % (inplanes, inplanes, size, size, batch),
+                                                        "launches_per_step": agg[0], "avg_launch_us": 1e6 * agg[1] / agg[0], "bound": "hbm", "achieved": agg[2] / agg[1] / 1e9,
+                                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": agg[2] / agg[1] / 1e9 / HBM_PEAK_GBS,
+                                                        "algorithmic_bytes_per_launch": agg[2] / agg[0]}
+            res["kernel_time_ms_per_step"] = 1e3 * tot
+            if breakdown_file:
+                with open(breakdown_file, "w") as f:
+                    f.write("== by kernel symbol ==\n%-64s %5s %10s %9s %9s %9s %7s\n" % ("kernel", "n", "total_ms", "avg_us", "GB/s", "TFLOP/s", "share"))
+                    for sy, (c_, t_, b_, fl_) in sorted(bysym.items(), key=lambda kv: -kv[1][1]):
+                        f.write("%-64s %5d %10.3f %9.1f %9.1f %9.1f %6.1f%%\n" % (sy, c_, 1e3 * t_, 1e6 * t_ / c_, b_ / max(t_, 1e-12) / 1e9, fl_ / max(t_, 1e-12) / 1e12, 100 * t_ / tot))
+                    f.write("\n== by (op, shape) ==\n%-14s %-62s %5s %10s %9s %9s %7s\n" % ("op", "shape", "n", "total_ms", "GB/s", "TFLOP/s", "share"))
+                    for (nm, sg), (c_, t_, b_, fl_) in sorted(prof.summary(by="shape").items(), key=lambda kv: -kv[1][1]):
+                        f.write("%-14s %-62s %5d %10.3f %9.1f %9.1f %6.1f%%\n" % (nm, sg, c_, 1e3 * t_, b_ / max(t_, 1e-12) / 1e9, fl_ / max(t_, 1e-12) / 1e12, 100 * t_ / tot))
+    del model, opt, reducer, x, lab, wgt
+    torch.cuda.empty_cache()
+    return res
+
+
+def main():
+    a = parse()
+    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ
+    if a.gpus > 1 and not launched:
+        return _self_launch(a)          # before ANY GPU call of this process
+    if a.dry_run:
+        return dry_run(a)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 or launched:
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    res = train_leg(a.model, a.inplanes, a.batch, a.size, a.dtype, a.steps, a.warmup, a.optimizer, world, rank, dev,
+                    not a.no_breakdown, a.breakdown_file)
+    solo = rank == 0 and world == 1
+    if solo and not a.no_extra_legs and a.model == "uresnet" and a.inplanes == 16:
+        # BASELINE configs[3] (ASPP_ResNet, 3 x 512 x 832; models/ASPP_ResNet.py:291) and the inplanes=32 network that
+        # training/train_ubresnet2018_wlarcv2.py:88 builds ("also report ip=32"), on this one GPU, a few steps each
+        for key, kind, ip in (("aspp", "aspp", 16), ("ip32", "uresnet", 32)):
+            try:
+                res[key] = train_leg(kind, ip, a.batch, 512, a.dtype, a.extra_steps, 3, a.optimizer, 1, 0, dev, not a.no_breakdown)
+            except Exception as e:          # a secondary leg must never take the headline line down
+                res[key] = {"error": repr(e)}
+    if solo and not a.no_infer:
         try:
             res["infer"] = infer_leg()
-        except Exception as e:          # the secondary leg must never take the headline line down
+        except Exception as e:
             res["infer"] = {"error": repr(e)}
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if solo and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(a.size, a.inplanes)
     if rank == 0:
         print(json.dumps(res), flush=True)

@@ -38,6 +38,10 @@ extern "C" {
  * the finalize / cast entry points sum the slots.  Callers allocate UBR_STAT_SLOTS * n doubles
  * and zero them (ubr_zero) before the first accumulating launch. */
 #define UBR_STAT_SLOTS 32
+/* The BatchNorm-backward / block-tail reduce passes launch at most 1024 workgroups and use only the first UBR_RED_SLOTS
+ * stripes of their buffer (the others stay zero, so ubr_bn_bwd_finalize still sums all of them): the apply passes with the
+ * finalize fused (ubr_*_apply_fin) re-sum the stripes in every workgroup, and 8 stripes keep that to 128 B per channel. */
+#define UBR_RED_SLOTS 8
 
 /* Strided NHWC view: element (n,y,x,c) lives at p + n*sn + y*sy + x*sx + c (strides in elements). */
 typedef struct {
@@ -216,6 +220,14 @@ int ubr_bn_bwd_apply(int dtype, int64_t npix, int C, const void* ga, int64_t ga_
                      const float* invstd, int relu, const float* k1, const float* k2,
                      void* gc, int64_t gc_ps, void* stream);
 
+/* pass 2 with the finalize fused: every workgroup forms k1 = sum(g_y)/count, k2 = sum(g_y*xhat)/count from the reduce pass's
+ * stripes itself and workgroup 0 writes dgamma / dbeta (either may be NULL) -- one launch less on the dependent chain.
+ * Needs 8*C bytes of LDS (C <= 8192). */
+int ubr_bn_bwd_apply_fin(int dtype, int64_t npix, int C, const void* ga, int64_t ga_ps, const void* ga2, int64_t ga2_ps,
+                         const void* c, int64_t c_ps, const float* scale, const float* shift, const float* mean,
+                         const float* invstd, int relu, const double* red, double count, float* dgamma, float* dbeta,
+                         void* gc, int64_t gc_ps, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * BasicBlock tail (models/common_layers.py:47-56):
  *   out = relu( relu(bn2(c2)) + shortcut ),  shortcut = bnpass(cb)  or  x
@@ -258,6 +270,17 @@ int ubr_block_tail_bwd_apply_masked(int dtype, int64_t npix, int C, const void* 
                                     const void* cb, int64_t cb_ps, const float* scale_b, const float* mean_b, const float* invstd_b,
                                     const float* k1_b, const float* k2_b,
                                     void* g_c2, int64_t g_c2_ps, void* g_sc, int64_t g_sc_ps, void* stream);
+
+/* masked apply pass with both finalizes fused (see ubr_bn_bwd_apply_fin); red2 / red_b are the reduce pass's buffers.
+ * On an identity block (cb == NULL) g_sc may be NULL: the skip gradient g_out*[out>0] is then not written, and the
+ * consumer re-forms it from g_out and the mask (ubr_conv_desc.addend_mask). */
+int ubr_block_tail_bwd_apply_fin(int dtype, int64_t npix, int C, const void* go, int64_t go_ps, const void* go2, int64_t go2_ps,
+                                 const uint8_t* relu_mask, const void* c2, int64_t c2_ps,
+                                 const float* scale2, const float* shift2, const float* mean2, const float* invstd2,
+                                 const double* red2, float* dgamma2, float* dbeta2,
+                                 const void* cb, int64_t cb_ps, const float* scale_b, const float* mean_b, const float* invstd_b,
+                                 const double* red_b, float* dgamma_b, float* dbeta_b, double count,
+                                 void* g_c2, int64_t g_c2_ps, void* g_sc, int64_t g_sc_ps, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * nn.MaxPool2d(3, stride, padding=1)  (models/ub_uresnet.py:44 stride 2; ASPP_ResNet.py:222 stride 1)

@@ -2,6 +2,7 @@
 the mirror modules keep the reference's constructor/state_dict surface, the tap geometry is right,
 the synthetic loader speaks the larcvdataset contract, and the product fails loudly without a GPU."""
 import os
+import sys
 import re
 
 import numpy as np
@@ -216,3 +217,19 @@ def test_data_parallel_wrappers_raise_instead_of_training_on_nothing():
     # forward-only use is unaffected by the checks (it still refuses CPU tensors)
     with torch.no_grad(), pytest.raises(RuntimeError, match="ROCm device"):
         m(x)
+
+
+def test_bench_self_launches_two_ranks_dry_run():
+    """`python bench.py --gpus 2` with no launcher environment starts its own ranks (before any GPU call), runs the bucketed
+    gradient exchange between them, and prints ONE JSON line from rank 0 -- rehearsed on CPU with gloo (--dry-run: no kernels)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["dry_run"] is True and d["exchange_ok"] is True
+    assert d["config"]["global_batch"] == 32 and d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak"

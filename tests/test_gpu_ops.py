@@ -321,7 +321,7 @@ def test_bn_finalize(dt):
 
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("bypass", [False, True])
-@pytest.mark.parametrize("C,N,H,W", [(16, 2, 12, 20), (96, 2, 12, 20), (16, 1, 96, 128)])
+@pytest.mark.parametrize("C,N,H,W", [(16, 2, 12, 20), (96, 2, 12, 20), (16, 1, 96, 128), (512, 1, 6, 10), (64, 1, 40, 24)])
 def test_block_tail(dt, bypass, C, N, H, W):
     """relu(relu(bn2(c2)) + shortcut) forward and the whole backward (both BatchNorms) vs autograd."""
     c2 = rnd(dt, gen(N, C, H, W, seed=1))
@@ -397,11 +397,45 @@ def test_block_tail(dt, bypass, C, N, H, W):
     torch.cuda.synchronize()
     assert torch.equal(g_c2m, g_c2) and torch.equal(g_scm, g_sc)
     assert torch.allclose(slotsum(red2m, 2 * C), slotsum(red2, 2 * C), rtol=1e-12, atol=1e-9)
+    # apply pass with both finalizes fused (no ubr_bn_bwd_finalize launch): bitwise the same gradients and dgamma / dbeta;
+    # with and without the second gradient operand (separate kernel instantiations)
+    for second in (go2d, None):
+        r2f, rbf = statbuf(2 * C), statbuf(2 * C)
+        ops.block_tail_bwd_reduce(go1d, second, junk, c2d, d(s2), d(t2), d(m2), d(i2), scd if bypass else None,
+                                  d(mb) if bypass else None, d(ib) if bypass else None, r2f, rbf if bypass else None, relu_mask=mask)
+        kf = torch.empty(4 * C, device=DEV)
+        e = [torch.empty(C, device=DEV) for _ in range(4)]
+        ops.bn_bwd_finalize(r2f, cnt, C, e[0], e[1], False, kf[:C], kf[C:2 * C])
+        if bypass:
+            ops.bn_bwd_finalize(rbf, cnt, C, e[2], e[3], False, kf[2 * C:3 * C], kf[3 * C:])
+        ga_, gs_ = torch.empty_like(g_c2), torch.empty_like(g_sc)
+        ops.block_tail_bwd_apply(go1d, second, junk, c2d, d(s2), d(t2), d(m2), d(i2), kf[:C], kf[C:2 * C],
+                                 scd if bypass else None, d(sb) if bypass else None, d(mb) if bypass else None, d(ib) if bypass else None,
+                                 kf[2 * C:3 * C] if bypass else None, kf[3 * C:] if bypass else None, ga_, gs_, relu_mask=mask)
+        f = [torch.full((C,), float("nan"), device=DEV) for _ in range(4)]
+        gb_, gt_ = torch.full_like(g_c2, float("nan")), torch.full_like(g_sc, float("nan"))
+        ops.block_tail_bwd_apply_fin(go1d, second, mask, c2d, d(s2), d(t2), d(m2), d(i2), r2f, f[0], f[1],
+                                     scd if bypass else None, d(sb) if bypass else None, d(mb) if bypass else None, d(ib) if bypass else None,
+                                     rbf if bypass else None, f[2] if bypass else None, f[3] if bypass else None, cnt, gb_, gt_)
+        torch.cuda.synchronize()
+        assert torch.equal(gb_, ga_) and torch.equal(gt_, gs_)
+        assert torch.equal(f[0], e[0]) and torch.equal(f[1], e[1])
+        if bypass:
+            assert torch.equal(f[2], e[2]) and torch.equal(f[3], e[3])
+        else:
+            # identity block: the skip gradient may be left to the consumer (g_sc = None)
+            gn_ = torch.full_like(g_c2, float("nan"))
+            ops.block_tail_bwd_apply_fin(go1d, second, mask, c2d, d(s2), d(t2), d(m2), d(i2), r2f, None, None,
+                                         None, None, None, None, None, None, None, cnt, gn_, None)
+            torch.cuda.synchronize()
+            assert torch.equal(gn_, ga_)
+        if second is not None:
+            assert torch.equal(ga_, g_c2)
 
 
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("relu", [True, False])
-@pytest.mark.parametrize("shape", [(2, 32, 10, 12), (1, 16, 96, 128)])
+@pytest.mark.parametrize("shape", [(2, 32, 10, 12), (1, 16, 96, 128), (1, 512, 6, 10), (2, 192, 5, 8)])
 def test_bn_backward(dt, relu, shape):
     N, C, H, W = shape
     c = rnd(dt, gen(N, C, H, W, seed=1))
@@ -428,6 +462,22 @@ def test_bn_backward(dt, relu, shape):
     close(nchw(gc), cr.grad, t, "g_c")
     close(dg.cpu(), gr.grad, t, "dgamma")
     close(db.cpu(), br.grad, t, "dbeta")
+    # finalize fused into the apply pass: bitwise the same; single-gradient instantiation against its own two-launch form
+    gcf, dgf, dbf = torch.full_like(gc, float("nan")), torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    ops.bn_bwd_apply_fin(gad, ga2d, cd, d(sc), d(sh), d(m), d(istd), relu, red, N * H * W, dgf, dbf, gcf)
+    torch.cuda.synchronize()
+    assert torch.equal(gcf, gc) and torch.equal(dgf, dg) and torch.equal(dbf, db)
+    red1 = statbuf(2 * C)
+    ops.bn_bwd_reduce(gad, None, cd, d(sc), d(sh), d(m), d(istd), relu, red1)
+    ops.bn_bwd_finalize(red1, N * H * W, C, dg, db, False, k[:C], k[C:])
+    ops.bn_bwd_apply(gad, None, cd, d(sc), d(sh), d(m), d(istd), relu, k[:C], k[C:], gc)
+    ops.bn_bwd_apply_fin(gad, None, cd, d(sc), d(sh), d(m), d(istd), relu, red1, N * H * W, dgf, dbf, gcf)
+    torch.cuda.synchronize()
+    assert torch.equal(gcf, gc) and torch.equal(dgf, dg) and torch.equal(dbf, db)
+    cr.grad = None
+    y = F.batch_norm(cr, None, None, gr, br, True, 0.1, 1e-5)
+    (F.relu(y) if relu else y).backward(ga)
+    close(nchw(gc), cr.grad, t, "g_c (one gradient operand)")
 
 
 @pytest.mark.parametrize("dt", DTS)

@@ -14,7 +14,10 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def symbol(name):
@@ -58,7 +61,9 @@ def main():
                       "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0}
     steps = 4          # bench.py --steps 3 --warmup 1
     per_step = sum(v["launches_profiled"] / steps * v["hbm_bytes_per_launch"] for v in kernels.values())
+    from ubresnet_amd.build import source_hash
     doc = {"dtype": "bf16", "batch": 16, "steps_profiled": steps, "hbm_bytes_per_step": per_step,
+           "csrc_sha256": source_hash(),      # bench.py reports these figures only while the kernel sources still hash to this
            "command": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-breakdown",
            "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE counts 128-B requests at 64 B)",
            "kernels": kernels}

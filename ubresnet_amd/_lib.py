@@ -18,6 +18,7 @@ LIB_PATH = os.environ.get("UBR_LIB", os.path.join(HERE, "libubresnet_hip.so"))  
 F32, BF16, F16 = 0, 1, 2
 MAX_TAPS = 64
 STAT_SLOTS = 32      # UBR_STAT_SLOTS
+RED_SLOTS = 8        # UBR_RED_SLOTS
 _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 _CPU = {F32: 4, BF16: 8, F16: 8}
 
@@ -89,6 +90,7 @@ SYMBOLS = [
     "ubr_bn_finalize", "ubr_bn_eval_affine", "ubr_bn_bwd_reduce", "ubr_bn_bwd_finalize", "ubr_bn_bwd_apply",
     "ubr_block_tail_fwd", "ubr_block_tail_bwd_reduce", "ubr_block_tail_bwd_apply",
     "ubr_block_tail_fwd_masked", "ubr_block_tail_bwd_reduce_masked", "ubr_block_tail_bwd_apply_masked",
+    "ubr_bn_bwd_apply_fin", "ubr_block_tail_bwd_apply_fin",
     "ubr_maxpool_fwd", "ubr_maxpool_bwd",
     "ubr_logsoftmax_bwd", "ubr_pixelwise_nll_fwd", "ubr_pixelwise_nll_bwd", "ubr_confusion",
     "ubr_channel_sum", "ubr_cast_f64_to_f32", "ubr_zero", "ubr_adam_step", "ubr_sgd_step", "ubr_crop_tiles", "ubr_stitch_tiles", "ubr_last_error", "ubr_version",
@@ -126,6 +128,9 @@ def _declare(lib):
     lib.ubr_bn_bwd_reduce.argtypes = [i32, i64, i32, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i32, vp, vp]
     lib.ubr_bn_bwd_finalize.argtypes = [vp, f64, vp, vp, i32, vp, vp, i32, vp, vp, vp]
     lib.ubr_bn_bwd_apply.argtypes = [i32, i64, i32, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i32, vp, vp, vp, i64, vp]
+    lib.ubr_bn_bwd_apply_fin.argtypes = [i32, i64, i32, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i32, vp, f64, vp, vp, vp, i64, vp]
+    lib.ubr_block_tail_bwd_apply_fin.argtypes = [i32, i64, i32, vp, i64, vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp,
+                                                 vp, i64, vp, vp, vp, vp, vp, vp, f64, vp, i64, vp, i64, vp]
     lib.ubr_block_tail_fwd.argtypes = [i32, i64, i32, vp, i64, vp, vp, vp, vp, i64, vp, vp, vp, vp, i64, vp]
     lib.ubr_block_tail_fwd_masked.argtypes = [i32, i64, i32, vp, i64, vp, vp, vp, vp, i64, vp, vp, vp, vp, i64, vp, vp]
     lib.ubr_block_tail_bwd_reduce_masked.argtypes = [i32, i64, i32, vp, i64, vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp]

@@ -20,6 +20,16 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-u
          "-fno-gpu-rdc", "-ffp-contract=off"]
 
 
+def source_hash():
+    """sha256 over the kernel sources and headers: stamps measurement files that are only valid for one build of the kernels"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(SOURCES) + sorted(HEADERS):
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()
+
+
 def _newer(target, deps):
     if not os.path.exists(target):
         return False

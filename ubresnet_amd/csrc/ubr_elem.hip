@@ -7,6 +7,7 @@
 #include "ubr_common.h"
 #include "ubr_host.h"
 #include <float.h>
+#include <string.h>
 
 namespace {
 
@@ -98,51 +99,156 @@ __device__ __forceinline__ void flush_sums(const float (*acc)[CPU], int c, int C
   }
 }
 
+// The same flush for power-of-two unit counts (every U-ResNet layer): lanes that hold the same channel unit are summed in
+// registers first (butterfly over the lane bits above log2(CU)), each wave writes ONE partial per channel to its own LDS row,
+// and the four rows are added in a fixed order -- no LDS atomics.  With CU = 2 (16 channels) the atomic form issued 32 fp64 LDS
+// atomics per thread, each a 32-way same-address conflict inside the wave.
+template <int CPU, int NQ>
+__device__ __forceinline__ void flush_sums_pow2(float (*acc)[CPU], int c, int CU, int C, float* lds, double* const* outs) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int m = CU; m < 64; m <<= 1) {
+#pragma unroll
+    for (int qn = 0; qn < NQ; ++qn)
+#pragma unroll
+      for (int e = 0; e < CPU; ++e) acc[qn][e] += __shfl_xor(acc[qn][e], m, 64);
+  }
+  // rows: [wave][qn][C]; with CU > 64 a wave covers only 64 of the units: rows are zeroed first
+  if (CU > 64) {
+    for (int i = threadIdx.x; i < 4 * NQ * C; i += 256) lds[i] = 0.f;
+    __syncthreads();
+  }
+  if (lane < CU) {
+#pragma unroll
+    for (int qn = 0; qn < NQ; ++qn)
+#pragma unroll
+      for (int e = 0; e < CPU; ++e) lds[(wave * NQ + qn) * C + c * CPU + e] = acc[qn][e];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NQ * C; i += 256) {
+    const int qn = i / C, ch = i - qn * C;
+    if (outs[qn] != nullptr) {
+      const double v = ((double)lds[(0 * NQ + qn) * C + ch] + (double)lds[(1 * NQ + qn) * C + ch]) +
+                       ((double)lds[(2 * NQ + qn) * C + ch] + (double)lds[(3 * NQ + qn) * C + ch]);
+      atomicAdd(&outs[qn][ch], v);
+    }
+  }
+}
+
+#ifdef UBR_TUNE
+static int g_tune_red_blocks = 0, g_tune_red_iters = 0, g_tune_flush = 1, g_tune_app_blocks = 0, g_tune_slots = 0;
+extern "C" void ubr_tune_set(const char* key, int v) {
+  if (!strcmp(key, "red_blocks")) g_tune_red_blocks = v;
+  if (!strcmp(key, "red_iters")) g_tune_red_iters = v;
+  if (!strcmp(key, "flush")) g_tune_flush = v;
+  if (!strcmp(key, "app_blocks")) g_tune_app_blocks = v;
+  if (!strcmp(key, "slots")) g_tune_slots = v;
+}
+#endif
+
+// ------------------------------------------------------------------------------------------
+// Streaming structure shared by the block-tail / BatchNorm kernels below.  A thread walks its channel unit down the pixels in
+// trips of UNR pixels: every 16-byte load of a trip (UNR pixels x 2-4 tensors) is issued before the first value is unpacked,
+// so a wave keeps 8-16 loads in flight instead of one or two.  (The first form of these kernels tested optional operands --
+// second gradient, bypass branch, mask -- with wave-uniform branches INSIDE the loop; the compiler then waited for each load
+// before the next branch, and the reduce passes ran at a third of HBM speed while their own apply passes, with more waves to
+// hide it, reached 60 %.)  Optional operands are template parameters here; a pixel beyond the end loads from an out-of-range
+// buffer offset (zeros) and its stores are dropped by the same range check, so trips need no remainder loop.
+// ------------------------------------------------------------------------------------------
+constexpr int kUnitOOR = (int)0x80000000;     // beyond any num_records: loads return zero, stores are dropped
+
+template <typename T, int UNR> struct UnitTrip {
+  __amdgpu_buffer_rsrc_t r;
+  unsigned off, step;
+  __device__ __forceinline__ UnitTrip(const void* base, long npix, long ps, const UnitIdx<T>& ix) {
+    constexpr unsigned ESZ = 16 / ET<T>::CPU;
+    r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, base != nullptr ? (int)(npix * ps * ESZ) : 0, 0x00020000);
+    off = (unsigned)ix.p * (unsigned)ps * ESZ + (unsigned)ix.c * 16u;
+    step = (unsigned)ix.pstep * (unsigned)ps * ESZ;
+  }
+  __device__ __forceinline__ void ld(ubr_u4 (&v)[UNR], const bool (&ok)[UNR]) const {
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(r, ok[u] ? (int)(off + (unsigned)u * step) : kUnitOOR, 0, 0);
+  }
+  __device__ __forceinline__ void st(int u, const float* f, bool ok) const {
+    const uint4 v = ET<T>::pack(f);
+    __builtin_amdgcn_raw_buffer_store_b128(ubr_u4{v.x, v.y, v.z, v.w}, r, ok ? (int)(off + (unsigned)u * step) : kUnitOOR, 0, 0);
+  }
+  __device__ __forceinline__ void next() { off += (unsigned)UNR * step; }
+};
+// the ReLU bit mask of a block tail: one byte per (pixel, unit)
+template <typename T, int UNR> struct MaskTrip {
+  __amdgpu_buffer_rsrc_t r;
+  unsigned off, step;
+  __device__ __forceinline__ MaskTrip(const uint8_t* base, long npix, int CU, const UnitIdx<T>& ix) {
+    r = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(base), 0, base != nullptr ? (int)(npix * CU) : 0, 0x00020000);
+    off = (unsigned)ix.p * (unsigned)CU + (unsigned)ix.c;
+    step = (unsigned)ix.pstep * (unsigned)CU;
+  }
+  __device__ __forceinline__ void ld(unsigned (&m)[UNR], const bool (&ok)[UNR]) const {
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) m[u] = __builtin_amdgcn_raw_buffer_load_b8(r, ok[u] ? (int)(off + (unsigned)u * step) : kUnitOOR, 0, 0);
+  }
+  __device__ __forceinline__ void st(int u, unsigned m, bool ok) const {
+    __builtin_amdgcn_raw_buffer_store_b8((unsigned char)m, r, ok ? (int)(off + (unsigned)u * step) : kUnitOOR, 0, 0);
+  }
+  __device__ __forceinline__ void next() { off += (unsigned)UNR * step; }
+};
+template <typename T> __device__ __forceinline__ void unpack4(const ubr_u4& v, float* f) { ET<T>::unpack(make_uint4(v.x, v.y, v.z, v.w), f); }
+
 // ------------------------------------------------------------------------------------------
 // BasicBlock tail forward
 // ------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void tail_fwd_kernel(long npix, int CU, const void* c2, long c2_ps, const float* m2p, const float* s2, const float* t2,
-                                                       const void* sc, long sc_ps, const float* mbp, const float* sb, const float* tb, void* out, long out_ps,
-                                                       uint8_t* relu_mask) {
+struct TailF {
+  long npix; int CU;
+  const void *c2, *sc; void* out; long c2_ps, sc_ps, out_ps;
+  const float *m2, *s2, *t2, *mb, *sb, *tb;
+  uint8_t* relu_mask;
+};
+template <typename T, bool BYP, bool MASK>
+__global__ __launch_bounds__(256) void tail_fwd_kernel(const TailF k) {
   constexpr int CPU = ET<T>::CPU;
-  UnitIdx<T> ix(CU);
   constexpr int H2 = CPU / 2;
+  constexpr int UNR = 4;
+  UnitIdx<T> ix(k.CU);
   ubr_f2 a2[H2], b2[H2], m2[H2], ab[H2], bb[H2], mb[H2];
-  ldconst2<CPU>(s2, ix.c, a2); ldconst2<CPU>(t2, ix.c, b2); ldconst2<CPU>(m2p, ix.c, m2);
-  const bool byp = sb != nullptr;
-  if (byp) { ldconst2<CPU>(sb, ix.c, ab); ldconst2<CPU>(tb, ix.c, bb); ldconst2<CPU>(mbp, ix.c, mb); }
-  UnitStream<T> C2(c2, npix, c2_ps, ix), SC(sc, npix, sc_ps, ix), OUT(out, npix, out_ps, ix);
-  unsigned moff = (unsigned)ix.p * (unsigned)CU + (unsigned)ix.c;
-  const unsigned mstep = (unsigned)ix.pstep * (unsigned)CU;
+  ldconst2<CPU>(k.s2, ix.c, a2); ldconst2<CPU>(k.t2, ix.c, b2); ldconst2<CPU>(k.m2, ix.c, m2);
+  if (BYP) { ldconst2<CPU>(k.sb, ix.c, ab); ldconst2<CPU>(k.tb, ix.c, bb); ldconst2<CPU>(k.mb, ix.c, mb); }
+  UnitTrip<T, UNR> C2(k.c2, k.npix, k.c2_ps, ix), SC(k.sc, k.npix, k.sc_ps, ix), OUT(k.out, k.npix, k.out_ps, ix);
+  MaskTrip<T, UNR> MK(k.relu_mask, k.npix, k.CU, ix);
   const float zero = 0.f;
-#pragma unroll 2
-  for (long p = ix.p; p < npix; p += ix.pstep) {
-    float v[CPU], s[CPU], o[CPU];
-    C2.ld(v); SC.ld(s);
+  for (long p = ix.p; p < k.npix; p += UNR * ix.pstep) {
+    bool ok[UNR];
 #pragma unroll
-    for (int h = 0; h < H2; ++h) {
-      // relu(bn2(c2)) + shortcut (through its own BatchNorm on a bypass block), relu: same operations as the scalar form
-      const ubr_f2 bn = __builtin_elementwise_fma(ubr_f2{v[2 * h], v[2 * h + 1]} - m2[h], a2[h], b2[h]);
-      const ubr_f2 r2 = {ubr_vmax(bn[0], zero), ubr_vmax(bn[1], zero)};
-      ubr_f2 sh = {s[2 * h], s[2 * h + 1]};
-      if (byp) sh = __builtin_elementwise_fma(sh - mb[h], ab[h], bb[h]);
-      const ubr_f2 t = r2 + sh;
-      o[2 * h] = ubr_vmax(t[0], zero); o[2 * h + 1] = ubr_vmax(t[1], zero);
-    }
-    OUT.st(o);
-    if (relu_mask != nullptr) {
-      // one bit per channel of this unit: "the STORED output is positive" (after rounding to the storage type, which is what the
-      // backward pass used to test on the tensor itself).  The backward's two passes then read 1 byte per unit instead of 16.
-      float r[CPU];
-      ET<T>::unpack(ET<T>::pack(o), r);
-      unsigned m = 0u;
+    for (int u = 0; u < UNR; ++u) ok[u] = p + u * ix.pstep < k.npix;
+    ubr_u4 rv[UNR], rs[UNR];
+    C2.ld(rv, ok); SC.ld(rs, ok);
 #pragma unroll
-      for (int e = 0; e < CPU; ++e) m |= (r[e] > 0.f ? 1u : 0u) << e;
-      relu_mask[moff] = (uint8_t)m;
-      moff += mstep;
+    for (int u = 0; u < UNR; ++u) {
+      float v[CPU], s[CPU], o[CPU];
+      unpack4<T>(rv[u], v); unpack4<T>(rs[u], s);
+#pragma unroll
+      for (int h = 0; h < H2; ++h) {
+        // relu(bn2(c2)) + shortcut (through its own BatchNorm on a bypass block), relu: same operations as the scalar form
+        const ubr_f2 bn = __builtin_elementwise_fma(ubr_f2{v[2 * h], v[2 * h + 1]} - m2[h], a2[h], b2[h]);
+        const ubr_f2 r2 = {ubr_vmax(bn[0], zero), ubr_vmax(bn[1], zero)};
+        ubr_f2 sh = {s[2 * h], s[2 * h + 1]};
+        if (BYP) sh = __builtin_elementwise_fma(sh - mb[h], ab[h], bb[h]);
+        const ubr_f2 t = r2 + sh;
+        o[2 * h] = ubr_vmax(t[0], zero); o[2 * h + 1] = ubr_vmax(t[1], zero);
+      }
+      OUT.st(u, o, ok[u]);
+      if (MASK) {
+        // one bit per channel of this unit: "the STORED output is positive" (after rounding to the storage type, which is what the
+        // backward pass used to test on the tensor itself).  The backward's two passes then read 1 byte per unit instead of 16.
+        float r[CPU];
+        ET<T>::unpack(ET<T>::pack(o), r);
+        unsigned m = 0u;
+#pragma unroll
+        for (int e = 0; e < CPU; ++e) m |= (r[e] > 0.f ? 1u : 0u) << e;
+        MK.st(u, m, ok[u]);
+      }
     }
-    C2.next(); SC.next(); OUT.next();
+    C2.next(); SC.next(); OUT.next(); MK.next();
   }
 }
 
@@ -158,86 +264,136 @@ struct TailB {
   double *red2, *redb;
   void *g_c2, *g_sc; long g_c2_ps, g_sc_ps;
   const uint8_t* relu_mask;      // optional: bit e of byte [pixel][unit] = (out > 0) for channel e of the unit; replaces the read of `out`
+  int flush;                     // reduce pass: 1 = register butterfly + per-wave LDS rows (flush_sums_pow2), 0 = LDS fp64 atomics
+  int nslots;                    // reduce pass: stripes of the fp64 accumulators in use (slot = blockIdx.x % nslots)
+  // apply pass, fused finalize (fin_red2 != nullptr): every workgroup sums the reduce pass's stripes itself (k1 = sum / count,
+  // k2 likewise), workgroup 0 also writes dgamma / dbeta -- no ubr_bn_bwd_finalize launch between the two passes
+  const double *fin_red2, *fin_redb; double count;
+  float *dgamma2, *dbeta2, *dgamma_b, *dbeta_b;
 };
 
-template <typename T, bool APPLY>
+// k1 / k2 of one BatchNorm site from the striped sums [slot][2 C] (sum g | sum g*xhat), into LDS floats kk[0..C) = k1, kk[C..2C) = k2
+__device__ __forceinline__ void fin_site(const double* red, int nslots, int C, double count, float* kk, float* dgamma, float* dbeta) {
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    double a = 0.0;
+    if (nslots == UBR_RED_SLOTS) {        // all stripe loads in flight at once (a runtime trip count makes them dependent round trips)
+      double v[UBR_RED_SLOTS];
+#pragma unroll
+      for (int sl = 0; sl < UBR_RED_SLOTS; ++sl) v[sl] = red[(size_t)sl * 2 * C + i];
+#pragma unroll
+      for (int sl = 0; sl < UBR_RED_SLOTS; ++sl) a += v[sl];
+    } else {
+      for (int sl = 0; sl < nslots; ++sl) a += red[(size_t)sl * 2 * C + i];
+    }
+    kk[i] = (float)(a / count);
+    if (blockIdx.x == 0) {
+      if (i < C) { if (dbeta != nullptr) dbeta[i] = (float)a; }
+      else if (dgamma != nullptr) dgamma[i - C] = (float)a;
+    }
+  }
+}
+
+template <typename T, bool APPLY, bool BYP, bool HAS_GO2, bool MASK>
 __global__ __launch_bounds__(256) void tail_bwd_kernel(const TailB k) {
   constexpr int CPU = ET<T>::CPU;
   constexpr int H2 = CPU / 2;
+  constexpr int UNR = APPLY ? 2 : 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   UnitIdx<T> ix(k.CU);
-  const bool byp = k.cb != nullptr;
   ubr_f2 s2[H2], t2[H2], m2[H2], i2[H2], mb[H2], ib[H2];
   ldconst2<CPU>(k.s2, ix.c, s2); ldconst2<CPU>(k.t2, ix.c, t2); ldconst2<CPU>(k.m2, ix.c, m2); ldconst2<CPU>(k.i2, ix.c, i2);
-  if (byp) { ldconst2<CPU>(k.mb, ix.c, mb); ldconst2<CPU>(k.ib, ix.c, ib); }
+  if (BYP) { ldconst2<CPU>(k.mb, ix.c, mb); ldconst2<CPU>(k.ib, ix.c, ib); }
   ubr_f2 k12[H2], k22[H2], k1b[H2], k2b[H2], sb[H2];
   if (APPLY) {
-    ldconst2<CPU>(k.k1_2, ix.c, k12); ldconst2<CPU>(k.k2_2, ix.c, k22);
-    if (byp) { ldconst2<CPU>(k.k1_b, ix.c, k1b); ldconst2<CPU>(k.k2_b, ix.c, k2b); ldconst2<CPU>(k.sb, ix.c, sb); }
+    if (k.fin_red2 != nullptr) {
+      float* kk = reinterpret_cast<float*>(smem);
+      fin_site(k.fin_red2, k.nslots, k.C, k.count, kk, k.dgamma2, k.dbeta2);
+      if (BYP) fin_site(k.fin_redb, k.nslots, k.C, k.count, kk + 2 * k.C, k.dgamma_b, k.dbeta_b);
+      __syncthreads();
+      ldconst2<CPU>(kk, ix.c, k12); ldconst2<CPU>(kk + k.C, ix.c, k22);
+      if (BYP) { ldconst2<CPU>(kk + 2 * k.C, ix.c, k1b); ldconst2<CPU>(kk + 3 * k.C, ix.c, k2b); }
+    } else {
+      ldconst2<CPU>(k.k1_2, ix.c, k12); ldconst2<CPU>(k.k2_2, ix.c, k22);
+      if (BYP) { ldconst2<CPU>(k.k1_b, ix.c, k1b); ldconst2<CPU>(k.k2_b, ix.c, k2b); }
+    }
+    if (BYP) ldconst2<CPU>(k.sb, ix.c, sb);
   }
   float acc[4][CPU];
 #pragma unroll
   for (int qn = 0; qn < 4; ++qn)
 #pragma unroll
     for (int e = 0; e < CPU; ++e) acc[qn][e] = 0.f;
-  UnitStream<T> GO(k.go, k.npix, k.go_ps, ix), GO2(k.go2, k.npix, k.go2_ps, ix), OUT(k.out, k.npix, k.out_ps, ix),
+  UnitTrip<T, UNR> GO(k.go, k.npix, k.go_ps, ix), GO2(k.go2, k.npix, k.go2_ps, ix), OUT(k.out, k.npix, k.out_ps, ix),
       C2(k.c2, k.npix, k.c2_ps, ix), CB(k.cb, k.npix, k.cb_ps, ix), GC2(k.g_c2, k.npix, k.g_c2_ps, ix), GSC(k.g_sc, k.npix, k.g_sc_ps, ix);
-  unsigned moff = (unsigned)ix.p * (unsigned)k.CU + (unsigned)ix.c;
-  const unsigned mstep = (unsigned)ix.pstep * (unsigned)k.CU;
+  MaskTrip<T, UNR> MK(k.relu_mask, k.npix, k.CU, ix);
+  const bool write_sc = k.g_sc != nullptr;
 
-#pragma unroll 2
-  for (long p = ix.p; p < k.npix; p += ix.pstep) {
-    float g[CPU], o[CPU], c2[CPU], cb[CPU];
-    GO.ld(g);
-    if (k.go2 != nullptr) {
-      float g2[CPU];
-      GO2.ld(g2);
+  for (long p = ix.p; p < k.npix; p += UNR * ix.pstep) {
+    bool ok[UNR];
 #pragma unroll
-      for (int e = 0; e < CPU; ++e) g[e] += g2[e];
-    }
-    unsigned mbits = 0u;
-    if (k.relu_mask != nullptr) { mbits = k.relu_mask[moff]; moff += mstep; }
-    else OUT.ld(o);
-    C2.ld(c2);
-    if (byp) CB.ld(cb);
-    float r2[CPU], rs[CPU];
+    for (int u = 0; u < UNR; ++u) ok[u] = p + u * ix.pstep < k.npix;
+    ubr_u4 rg[UNR], rg2[HAS_GO2 ? UNR : 1], ro[MASK ? 1 : UNR], rc2[UNR], rcb[BYP ? UNR : 1];
+    unsigned rm[UNR];
+    GO.ld(rg, ok);
+    if constexpr (HAS_GO2) GO2.ld(rg2, ok);
+    if constexpr (MASK) MK.ld(rm, ok); else OUT.ld(ro, ok);
+    C2.ld(rc2, ok);
+    if constexpr (BYP) CB.ld(rcb, ok);
 #pragma unroll
-    for (int h = 0; h < H2; ++h) {
-      // (the same operations, in the same order, as the scalar form: out > 0 gates the incoming gradient, relu(bn2) gates the
-      // branch through conv2; xh = (c - mean) * invstd; apply: s * (gy - k1 - xh * k2))
-      const ubr_f2 d2 = ubr_f2{c2[2 * h], c2[2 * h + 1]} - m2[h];
-      const ubr_f2 bn = __builtin_elementwise_fma(d2, s2[h], t2[h]);
-      const ubr_f2 xh2 = d2 * i2[h];
-      const bool p0 = k.relu_mask != nullptr ? ((mbits >> (2 * h)) & 1u) != 0u : o[2 * h] > 0.f;
-      const bool p1 = k.relu_mask != nullptr ? ((mbits >> (2 * h + 1)) & 1u) != 0u : o[2 * h + 1] > 0.f;
-      const ubr_f2 gz = {p0 ? g[2 * h] : 0.f, p1 ? g[2 * h + 1] : 0.f};
-      const ubr_f2 gy2 = {bn[0] > 0.f ? gz[0] : 0.f, bn[1] > 0.f ? gz[1] : 0.f};
-      ubr_f2 xhb = {0.f, 0.f};
-      if (byp) xhb = (ubr_f2{cb[2 * h], cb[2 * h + 1]} - mb[h]) * ib[h];
-      if (APPLY) {
-        const ubr_f2 a = s2[h] * (gy2 - k12[h] - xh2 * k22[h]);
-        r2[2 * h] = a[0]; r2[2 * h + 1] = a[1];
-        ubr_f2 b = gz;
-        if (byp) b = sb[h] * (gz - k1b[h] - xhb * k2b[h]);
-        rs[2 * h] = b[0]; rs[2 * h + 1] = b[1];
-      } else {
-        const ubr_f2 gx = gy2 * xh2;
-        acc[0][2 * h] += gy2[0]; acc[0][2 * h + 1] += gy2[1];
-        acc[1][2 * h] += gx[0]; acc[1][2 * h + 1] += gx[1];
-        if (byp) {
-          const ubr_f2 gb = gz * xhb;
-          acc[2][2 * h] += gz[0]; acc[2][2 * h + 1] += gz[1];
-          acc[3][2 * h] += gb[0]; acc[3][2 * h + 1] += gb[1];
+    for (int u = 0; u < UNR; ++u) {
+      float g[CPU], o[CPU], c2[CPU], cb[CPU];
+      unpack4<T>(rg[u], g);
+      if constexpr (HAS_GO2) {
+        float g2[CPU];
+        unpack4<T>(rg2[u], g2);
+#pragma unroll
+        for (int e = 0; e < CPU; ++e) g[e] += g2[e];
+      }
+      unsigned mbits = 0u;
+      if constexpr (MASK) mbits = rm[u]; else unpack4<T>(ro[u], o);
+      unpack4<T>(rc2[u], c2);
+      if constexpr (BYP) unpack4<T>(rcb[u], cb);
+      float r2[CPU], rs[CPU];
+#pragma unroll
+      for (int h = 0; h < H2; ++h) {
+        // (the same operations, in the same order, as the scalar form: out > 0 gates the incoming gradient, relu(bn2) gates the
+        // branch through conv2; xh = (c - mean) * invstd; apply: s * (gy - k1 - xh * k2))
+        const ubr_f2 d2 = ubr_f2{c2[2 * h], c2[2 * h + 1]} - m2[h];
+        const ubr_f2 bn = __builtin_elementwise_fma(d2, s2[h], t2[h]);
+        const ubr_f2 xh2 = d2 * i2[h];
+        const bool p0 = MASK ? ((mbits >> (2 * h)) & 1u) != 0u : o[2 * h] > 0.f;
+        const bool p1 = MASK ? ((mbits >> (2 * h + 1)) & 1u) != 0u : o[2 * h + 1] > 0.f;
+        const ubr_f2 gz = {p0 ? g[2 * h] : 0.f, p1 ? g[2 * h + 1] : 0.f};
+        const ubr_f2 gy2 = {bn[0] > 0.f ? gz[0] : 0.f, bn[1] > 0.f ? gz[1] : 0.f};
+        ubr_f2 xhb = {0.f, 0.f};
+        if (BYP) xhb = (ubr_f2{cb[2 * h], cb[2 * h + 1]} - mb[h]) * ib[h];
+        if (APPLY) {
+          const ubr_f2 a = s2[h] * (gy2 - k12[h] - xh2 * k22[h]);
+          r2[2 * h] = a[0]; r2[2 * h + 1] = a[1];
+          ubr_f2 b = gz;
+          if (BYP) b = sb[h] * (gz - k1b[h] - xhb * k2b[h]);
+          rs[2 * h] = b[0]; rs[2 * h + 1] = b[1];
+        } else {
+          const ubr_f2 gx = gy2 * xh2;
+          acc[0][2 * h] += gy2[0]; acc[0][2 * h + 1] += gy2[1];
+          acc[1][2 * h] += gx[0]; acc[1][2 * h + 1] += gx[1];
+          if (BYP) {
+            const ubr_f2 gb = gz * xhb;
+            acc[2][2 * h] += gz[0]; acc[2][2 * h + 1] += gz[1];
+            acc[3][2 * h] += gb[0]; acc[3][2 * h + 1] += gb[1];
+          }
         }
       }
+      if (APPLY) { GC2.st(u, r2, ok[u]); if (write_sc) GSC.st(u, rs, ok[u]); }
     }
-    if (APPLY) { GC2.st(r2); GSC.st(rs); GC2.next(); GSC.next(); }
-    GO.next(); GO2.next(); OUT.next(); C2.next(); CB.next();
+    GO.next(); GO2.next(); OUT.next(); C2.next(); CB.next(); MK.next();
+    if (APPLY) { GC2.next(); GSC.next(); }
   }
   if (!APPLY) {
-    const size_t so = (size_t)(blockIdx.x % UBR_STAT_SLOTS) * 2 * k.C;
-    double* outs[4] = {k.red2 + so, k.red2 + so + k.C, byp ? k.redb + so : nullptr, byp ? k.redb + so + k.C : nullptr};
-    flush_sums<CPU, 4>(acc, ix.c, k.C, reinterpret_cast<double*>(smem), outs);
+    const size_t so = (size_t)(blockIdx.x % k.nslots) * 2 * k.C;
+    double* outs[4] = {k.red2 + so, k.red2 + so + k.C, BYP ? k.redb + so : nullptr, BYP ? k.redb + so + k.C : nullptr};
+    if (k.flush) flush_sums_pow2<CPU, 4>(acc, ix.c, k.CU, k.C, reinterpret_cast<float*>(smem), outs);
+    else flush_sums<CPU, 4>(acc, ix.c, k.C, reinterpret_cast<double*>(smem), outs);
   }
 }
 
@@ -245,57 +401,80 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(const TailB k) {
 // BatchNorm(+ReLU) backward: a = max(bn(c), 0)
 // ------------------------------------------------------------------------------------------
 struct BnB {
-  long npix; int C, CU, relu;
+  long npix; int C, CU;
   const void *ga, *ga2, *c; long ga_ps, ga2_ps, c_ps;
   const float *scale, *shift, *mean, *invstd, *k1, *k2;
   double* red; void* gc; long gc_ps;
+  int flush, nslots;
+  const double* fin_red; double count; float *dgamma, *dbeta;     // apply pass with the finalize fused (see TailB)
 };
-template <typename T, bool APPLY>
+template <typename T, bool APPLY, bool HAS_GA2, bool RELU>
 __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnB k) {
   constexpr int CPU = ET<T>::CPU;
   constexpr int H2 = CPU / 2;
+  constexpr int UNR = 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   UnitIdx<T> ix(k.CU);
   ubr_f2 sc[H2], sh[H2], mu[H2], is[H2], k1[H2], k2[H2];
   ldconst2<CPU>(k.scale, ix.c, sc); ldconst2<CPU>(k.shift, ix.c, sh); ldconst2<CPU>(k.mean, ix.c, mu); ldconst2<CPU>(k.invstd, ix.c, is);
-  if (APPLY) { ldconst2<CPU>(k.k1, ix.c, k1); ldconst2<CPU>(k.k2, ix.c, k2); }
+  if (APPLY) {
+    if (k.fin_red != nullptr) {
+      float* kk = reinterpret_cast<float*>(smem);
+      fin_site(k.fin_red, k.nslots, k.C, k.count, kk, k.dgamma, k.dbeta);
+      __syncthreads();
+      ldconst2<CPU>(kk, ix.c, k1); ldconst2<CPU>(kk + k.C, ix.c, k2);
+    } else {
+      ldconst2<CPU>(k.k1, ix.c, k1); ldconst2<CPU>(k.k2, ix.c, k2);
+    }
+  }
   float acc[2][CPU];
 #pragma unroll
   for (int e = 0; e < CPU; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
-  UnitStream<T> GA(k.ga, k.npix, k.ga_ps, ix), GA2(k.ga2, k.npix, k.ga2_ps, ix), CC(k.c, k.npix, k.c_ps, ix), GC(k.gc, k.npix, k.gc_ps, ix);
-#pragma unroll 2
-  for (long p = ix.p; p < k.npix; p += ix.pstep) {
-    float g[CPU], c[CPU], r[CPU];
-    GA.ld(g);
-    if (k.ga2 != nullptr) {
-      float g2[CPU];
-      GA2.ld(g2);
+  UnitTrip<T, UNR> GA(k.ga, k.npix, k.ga_ps, ix), GA2(k.ga2, k.npix, k.ga2_ps, ix), CC(k.c, k.npix, k.c_ps, ix), GC(k.gc, k.npix, k.gc_ps, ix);
+  for (long p = ix.p; p < k.npix; p += UNR * ix.pstep) {
+    bool ok[UNR];
 #pragma unroll
-      for (int e = 0; e < CPU; ++e) g[e] += g2[e];
-    }
-    CC.ld(c);
+    for (int u = 0; u < UNR; ++u) ok[u] = p + u * ix.pstep < k.npix;
+    ubr_u4 rg[UNR], rg2[HAS_GA2 ? UNR : 1], rc[UNR];
+    GA.ld(rg, ok);
+    if constexpr (HAS_GA2) GA2.ld(rg2, ok);
+    CC.ld(rc, ok);
 #pragma unroll
-    for (int h = 0; h < H2; ++h) {
-      const ubr_f2 d = ubr_f2{c[2 * h], c[2 * h + 1]} - mu[h];
-      const ubr_f2 bn = __builtin_elementwise_fma(d, sc[h], sh[h]);
-      const ubr_f2 xh = d * is[h];
-      const ubr_f2 gy = {(!k.relu || bn[0] > 0.f) ? g[2 * h] : 0.f, (!k.relu || bn[1] > 0.f) ? g[2 * h + 1] : 0.f};
-      if (APPLY) {
-        const ubr_f2 a = sc[h] * (gy - k1[h] - xh * k2[h]);
-        r[2 * h] = a[0]; r[2 * h + 1] = a[1];
-      } else {
-        const ubr_f2 gx = gy * xh;
-        acc[0][2 * h] += gy[0]; acc[0][2 * h + 1] += gy[1];
-        acc[1][2 * h] += gx[0]; acc[1][2 * h + 1] += gx[1];
+    for (int u = 0; u < UNR; ++u) {
+      float g[CPU], c[CPU], r[CPU];
+      unpack4<T>(rg[u], g);
+      if constexpr (HAS_GA2) {
+        float g2[CPU];
+        unpack4<T>(rg2[u], g2);
+#pragma unroll
+        for (int e = 0; e < CPU; ++e) g[e] += g2[e];
       }
+      unpack4<T>(rc[u], c);
+#pragma unroll
+      for (int h = 0; h < H2; ++h) {
+        const ubr_f2 d = ubr_f2{c[2 * h], c[2 * h + 1]} - mu[h];
+        const ubr_f2 bn = __builtin_elementwise_fma(d, sc[h], sh[h]);
+        const ubr_f2 xh = d * is[h];
+        const ubr_f2 gy = {(!RELU || bn[0] > 0.f) ? g[2 * h] : 0.f, (!RELU || bn[1] > 0.f) ? g[2 * h + 1] : 0.f};
+        if (APPLY) {
+          const ubr_f2 a = sc[h] * (gy - k1[h] - xh * k2[h]);
+          r[2 * h] = a[0]; r[2 * h + 1] = a[1];
+        } else {
+          const ubr_f2 gx = gy * xh;
+          acc[0][2 * h] += gy[0]; acc[0][2 * h + 1] += gy[1];
+          acc[1][2 * h] += gx[0]; acc[1][2 * h + 1] += gx[1];
+        }
+      }
+      if (APPLY) GC.st(u, r, ok[u]);
     }
-    if (APPLY) { GC.st(r); GC.next(); }
     GA.next(); GA2.next(); CC.next();
+    if (APPLY) GC.next();
   }
   if (!APPLY) {
-    const size_t so = (size_t)(blockIdx.x % UBR_STAT_SLOTS) * 2 * k.C;
+    const size_t so = (size_t)(blockIdx.x % k.nslots) * 2 * k.C;
     double* outs[2] = {k.red + so, k.red + so + k.C};
-    flush_sums<CPU, 2>(acc, ix.c, k.C, reinterpret_cast<double*>(smem), outs);
+    if (k.flush) flush_sums_pow2<CPU, 2>(acc, ix.c, k.CU, k.C, reinterpret_cast<float*>(smem), outs);
+    else flush_sums<CPU, 2>(acc, ix.c, k.C, reinterpret_cast<double*>(smem), outs);
   }
 }
 
@@ -675,6 +854,13 @@ template <typename K> struct Dispatch3 {};
     default: { typedef f16_t TT; CALL; } break;       \
   }
 
+// reduce passes: the register-butterfly flush needs a thread's lane-mates to hold the same unit (power-of-two unit counts below
+// a wave) or one unit per lane (>= 64 units); its four per-wave rows must fit the LDS carve-out sized for the atomic form
+static int red_flush_mode(int CU, int C, int NQ) {
+  const bool pow2 = (CU & (CU - 1)) == 0;
+  return ((CU >= 64 || pow2) && (size_t)16 * NQ * C <= 65536) ? 1 : 0;
+}
+
 static int check_nhwc(const char* who, int dtype, int64_t npix, int C, const void* p, int64_t ps) {
   UBR_CHECK(ubr_dtype_ok(dtype), "%s: bad dtype", who);
   const int esz = ubr_esize(dtype);
@@ -685,6 +871,16 @@ static int check_nhwc(const char* who, int dtype, int64_t npix, int C, const voi
 }
 #define UBR_TRY(x) do { int rc__ = (x); if (rc__ != UBR_OK) return rc__; } while (0)
 
+#define UBR_BOOL2(b0, b1, CALL)                                                          \
+  do {                                                                                   \
+    if (b0) { constexpr bool B0 = true; if (b1) { constexpr bool B1 = true; CALL; } else { constexpr bool B1 = false; CALL; } } \
+    else { constexpr bool B0 = false; if (b1) { constexpr bool B1 = true; CALL; } else { constexpr bool B1 = false; CALL; } }   \
+  } while (0)
+#define UBR_BOOL3(b0, b1, b2, CALL)                                                      \
+  do {                                                                                   \
+    if (b2) { constexpr bool B2 = true; UBR_BOOL2(b0, b1, CALL); } else { constexpr bool B2 = false; UBR_BOOL2(b0, b1, CALL); } \
+  } while (0)
+
 static int tail_fwd_common(int dtype, int64_t npix, int C, const void* c2, int64_t c2_ps, const float* mean2, const float* scale2,
                            const float* shift2, const void* sc, int64_t sc_ps, const float* mean_b, const float* scale_b,
                            const float* shift_b, void* out, int64_t out_ps, uint8_t* relu_mask, void* stream) {
@@ -692,10 +888,13 @@ static int tail_fwd_common(int dtype, int64_t npix, int C, const void* c2, int64
   UBR_TRY(check_nhwc("ubr_block_tail_fwd(sc)", dtype, npix, C, sc, sc_ps));
   UBR_TRY(check_nhwc("ubr_block_tail_fwd(out)", dtype, npix, C, out, out_ps));
   UBR_CHECK(mean2 && scale2 && shift2 && ((scale_b == nullptr) == (shift_b == nullptr)) && ((scale_b == nullptr) == (mean_b == nullptr)), "ubr_block_tail_fwd: bad affine pointers");
-  const int CU = C / ubr_cpu(dtype);
-  const int blocks = pick_blocks(npix, CU);
-  UBR_DT_SWITCH(dtype, ubr_launch(tail_fwd_kernel<TT>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (long)npix, CU, c2, (long)c2_ps,
-                                          mean2, scale2, shift2, sc, (long)sc_ps, mean_b, scale_b, shift_b, out, (long)out_ps, relu_mask));
+  TailF k{};
+  k.npix = npix; k.CU = C / ubr_cpu(dtype);
+  k.c2 = c2; k.sc = sc; k.out = out; k.c2_ps = c2_ps; k.sc_ps = sc_ps; k.out_ps = out_ps;
+  k.m2 = mean2; k.s2 = scale2; k.t2 = shift2; k.mb = mean_b; k.sb = scale_b; k.tb = shift_b; k.relu_mask = relu_mask;
+  const int blocks = pick_blocks(npix, k.CU, 2048, 4);
+  const bool byp = scale_b != nullptr, msk = relu_mask != nullptr;
+  UBR_DT_SWITCH(dtype, UBR_BOOL2(byp, msk, ubr_launch((tail_fwd_kernel<TT, B0, B1>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, k)));
   UBR_LAUNCH_CHECK("ubr_block_tail_fwd");
   return UBR_OK;
 }
@@ -711,13 +910,16 @@ extern "C" int ubr_block_tail_fwd_masked(int dtype, int64_t npix, int C, const v
   return tail_fwd_common(dtype, npix, C, c2, c2_ps, mean2, scale2, shift2, sc, sc_ps, mean_b, scale_b, shift_b, out, out_ps, relu_mask, stream);
 }
 
+struct TailFin { const double *red2, *redb; double count; float *dgamma2, *dbeta2, *dgamma_b, *dbeta_b; };
+
 static int tail_bwd_common(bool apply, int dtype, int64_t npix, int C, const void* go, int64_t go_ps, const void* go2, int64_t go2_ps,
                            const void* out, int64_t out_ps, const void* c2, int64_t c2_ps,
                            const float* scale2, const float* shift2, const float* mean2, const float* invstd2,
                            const float* k1_2, const float* k2_2,
                            const void* cb, int64_t cb_ps, const float* scale_b, const float* mean_b, const float* invstd_b,
                            const float* k1_b, const float* k2_b, double* red2, double* red_b,
-                           void* g_c2, int64_t g_c2_ps, void* g_sc, int64_t g_sc_ps, void* stream, const uint8_t* relu_mask = nullptr) {
+                           void* g_c2, int64_t g_c2_ps, void* g_sc, int64_t g_sc_ps, void* stream, const uint8_t* relu_mask = nullptr,
+                           const TailFin* fin = nullptr) {
   const char* who = apply ? "ubr_block_tail_bwd_apply" : "ubr_block_tail_bwd_reduce";
   UBR_TRY(check_nhwc(who, dtype, npix, C, go, go_ps));
   if (go2) UBR_TRY(check_nhwc(who, dtype, npix, C, go2, go2_ps));
@@ -726,10 +928,13 @@ static int tail_bwd_common(bool apply, int dtype, int64_t npix, int C, const voi
   if (cb) UBR_TRY(check_nhwc(who, dtype, npix, C, cb, cb_ps));
   UBR_CHECK(scale2 && shift2 && mean2 && invstd2, "%s: null bn2 constants", who);
   if (cb) UBR_CHECK(mean_b && invstd_b, "%s: null bnpass constants", who);
+  if (relu_mask) UBR_CHECK(npix * (C / ubr_cpu(dtype)) < (int64_t)1 << 31, "%s: mask exceeds 2 GiB", who);
   if (apply) {
     UBR_TRY(check_nhwc(who, dtype, npix, C, g_c2, g_c2_ps));
-    UBR_TRY(check_nhwc(who, dtype, npix, C, g_sc, g_sc_ps));
-    UBR_CHECK(k1_2 && k2_2 && (!cb || (k1_b && k2_b && scale_b)), "%s: null backward constants", who);
+    if (g_sc != nullptr || cb != nullptr) UBR_TRY(check_nhwc(who, dtype, npix, C, g_sc, g_sc_ps));
+    if (fin == nullptr) UBR_CHECK(k1_2 && k2_2 && (!cb || (k1_b && k2_b)), "%s: null backward constants", who);
+    else UBR_CHECK(fin->red2 && (!cb || fin->redb) && fin->count >= 1.0 && (size_t)16 * C <= 65536, "%s: bad fused-finalize arguments", who);
+    UBR_CHECK(!cb || scale_b, "%s: null bnpass scale", who);
   } else {
     UBR_CHECK(red2 && (!cb || red_b), "%s: null reduction buffer", who);
   }
@@ -741,11 +946,26 @@ static int tail_bwd_common(bool apply, int dtype, int64_t npix, int C, const voi
   k.sb = scale_b; k.mb = mean_b; k.ib = invstd_b; k.k1_b = k1_b; k.k2_b = k2_b;
   k.red2 = red2; k.redb = red_b; k.g_c2 = g_c2; k.g_sc = g_sc; k.g_c2_ps = g_c2_ps; k.g_sc_ps = g_sc_ps;
   k.relu_mask = relu_mask;
-  static const int red_iters = [] { const char* e = getenv("UBR_RED_ITERS"); return e ? atoi(e) : 8; }();
-  const int blocks = pick_blocks(npix, k.CU, apply ? 2048 : 512, apply ? 1 : red_iters);
-  const size_t lds = apply ? 0 : (size_t)4 * C * sizeof(double);
-  if (apply) { UBR_DT_SWITCH(dtype, ubr_launch((tail_bwd_kernel<TT, true>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, k)); }
-  else { UBR_DT_SWITCH(dtype, ubr_launch((tail_bwd_kernel<TT, false>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, k)); }
+  k.nslots = UBR_RED_SLOTS;
+  if (fin != nullptr) {
+    k.fin_red2 = fin->red2; k.fin_redb = fin->redb; k.count = fin->count;
+    k.dgamma2 = fin->dgamma2; k.dbeta2 = fin->dbeta2; k.dgamma_b = fin->dgamma_b; k.dbeta_b = fin->dbeta_b;
+  }
+  int red_iters = 8, red_blocks = 512, app_blocks = 2048;
+  k.flush = red_flush_mode(k.CU, C, 4);
+#ifdef UBR_TUNE
+  if (g_tune_red_iters) red_iters = g_tune_red_iters;
+  if (g_tune_red_blocks) red_blocks = g_tune_red_blocks;
+  if (g_tune_app_blocks) app_blocks = g_tune_app_blocks;
+  if (g_tune_slots) k.nslots = g_tune_slots;
+  if (!g_tune_flush) k.flush = 0;
+#endif
+  const int blocks = pick_blocks(npix, k.CU, apply ? app_blocks : red_blocks, apply ? 2 : red_iters);
+  // reduce: fp64 atomics need 4 C doubles, the per-wave rows 4 x 4 C floats; apply with the finalize fused: 4 C floats
+  const size_t lds = apply ? (fin != nullptr ? (size_t)16 * C : 0) : (size_t)(k.flush ? 16 : 8) * 4 * C;
+  const bool byp = cb != nullptr, g2 = go2 != nullptr, msk = relu_mask != nullptr;
+  if (apply) { UBR_DT_SWITCH(dtype, UBR_BOOL3(byp, g2, msk, ubr_launch((tail_bwd_kernel<TT, true, B0, B1, B2>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, k))); }
+  else { UBR_DT_SWITCH(dtype, UBR_BOOL3(byp, g2, msk, ubr_launch((tail_bwd_kernel<TT, false, B0, B1, B2>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, k))); }
   UBR_LAUNCH_CHECK(who);
   return UBR_OK;
 }
@@ -794,26 +1014,42 @@ extern "C" int ubr_block_tail_bwd_apply_masked(int dtype, int64_t npix, int C, c
                          g_c2, g_c2_ps, g_sc, g_sc_ps, stream, relu_mask);
 }
 
+struct BnFin { const double* red; double count; float *dgamma, *dbeta; };
+
 static int bn_bwd_common(bool apply, int dtype, int64_t npix, int C, const void* ga, int64_t ga_ps, const void* ga2, int64_t ga2_ps,
                          const void* c, int64_t c_ps, const float* scale, const float* shift, const float* mean,
                          const float* invstd, int relu, const float* k1, const float* k2, double* red,
-                         void* gc, int64_t gc_ps, void* stream) {
+                         void* gc, int64_t gc_ps, void* stream, const BnFin* fin = nullptr) {
   const char* who = apply ? "ubr_bn_bwd_apply" : "ubr_bn_bwd_reduce";
   UBR_TRY(check_nhwc(who, dtype, npix, C, ga, ga_ps));
   if (ga2) UBR_TRY(check_nhwc(who, dtype, npix, C, ga2, ga2_ps));
   UBR_TRY(check_nhwc(who, dtype, npix, C, c, c_ps));
   UBR_CHECK(scale && shift && mean && invstd, "%s: null bn constants", who);
-  if (apply) { UBR_TRY(check_nhwc(who, dtype, npix, C, gc, gc_ps)); UBR_CHECK(k1 && k2, "%s: null k1/k2", who); }
-  else UBR_CHECK(red != nullptr, "%s: null reduction buffer", who);
+  if (apply) {
+    UBR_TRY(check_nhwc(who, dtype, npix, C, gc, gc_ps));
+    if (fin == nullptr) UBR_CHECK(k1 && k2, "%s: null k1/k2", who);
+    else UBR_CHECK(fin->red && fin->count >= 1.0 && (size_t)8 * C <= 65536, "%s: bad fused-finalize arguments", who);
+  } else UBR_CHECK(red != nullptr, "%s: null reduction buffer", who);
   BnB k{};
-  k.npix = npix; k.C = C; k.CU = C / ubr_cpu(dtype); k.relu = relu;
+  k.npix = npix; k.C = C; k.CU = C / ubr_cpu(dtype);
   k.ga = ga; k.ga2 = ga2; k.c = c; k.ga_ps = ga_ps; k.ga2_ps = ga2_ps; k.c_ps = c_ps;
   k.scale = scale; k.shift = shift; k.mean = mean; k.invstd = invstd; k.k1 = k1; k.k2 = k2; k.red = red; k.gc = gc; k.gc_ps = gc_ps;
-  static const int red_iters = [] { const char* e = getenv("UBR_RED_ITERS"); return e ? atoi(e) : 8; }();
-  const int blocks = pick_blocks(npix, k.CU, apply ? 2048 : 1024, apply ? 1 : red_iters);
-  const size_t lds = apply ? 0 : (size_t)2 * C * sizeof(double);
-  if (apply) { UBR_DT_SWITCH(dtype, ubr_launch((bn_bwd_kernel<TT, true>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, k)); }
-  else { UBR_DT_SWITCH(dtype, ubr_launch((bn_bwd_kernel<TT, false>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, k)); }
+  k.nslots = UBR_RED_SLOTS;
+  if (fin != nullptr) { k.fin_red = fin->red; k.count = fin->count; k.dgamma = fin->dgamma; k.dbeta = fin->dbeta; }
+  int red_iters = 8, red_blocks = 512, app_blocks = 2048;
+  k.flush = red_flush_mode(k.CU, C, 2);
+#ifdef UBR_TUNE
+  if (g_tune_red_iters) red_iters = g_tune_red_iters;
+  if (g_tune_red_blocks) red_blocks = g_tune_red_blocks;
+  if (g_tune_app_blocks) app_blocks = g_tune_app_blocks;
+  if (g_tune_slots) k.nslots = g_tune_slots;
+  if (!g_tune_flush) k.flush = 0;
+#endif
+  const int blocks = pick_blocks(npix, k.CU, apply ? app_blocks : red_blocks, apply ? 4 : red_iters);
+  const size_t lds = apply ? (fin != nullptr ? (size_t)8 * C : 0) : (size_t)(k.flush ? 16 : 8) * 2 * C;
+  const bool g2 = ga2 != nullptr, rl = relu != 0;
+  if (apply) { UBR_DT_SWITCH(dtype, UBR_BOOL2(g2, rl, ubr_launch((bn_bwd_kernel<TT, true, B0, B1>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, k))); }
+  else { UBR_DT_SWITCH(dtype, UBR_BOOL2(g2, rl, ubr_launch((bn_bwd_kernel<TT, false, B0, B1>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, k))); }
   UBR_LAUNCH_CHECK(who);
   return UBR_OK;
 }
@@ -827,6 +1063,29 @@ extern "C" int ubr_bn_bwd_apply(int dtype, int64_t npix, int C, const void* ga, 
                                 const float* invstd, int relu, const float* k1, const float* k2,
                                 void* gc, int64_t gc_ps, void* stream) {
   return bn_bwd_common(true, dtype, npix, C, ga, ga_ps, ga2, ga2_ps, c, c_ps, scale, shift, mean, invstd, relu, k1, k2, nullptr, gc, gc_ps, stream);
+}
+
+// Apply passes with the finalize fused (no ubr_bn_bwd_finalize launch between reduce and apply): `red` is what the reduce pass
+// accumulated; every workgroup forms k1 / k2 from it, workgroup 0 writes dgamma / dbeta.
+extern "C" int ubr_bn_bwd_apply_fin(int dtype, int64_t npix, int C, const void* ga, int64_t ga_ps, const void* ga2, int64_t ga2_ps,
+                                    const void* c, int64_t c_ps, const float* scale, const float* shift, const float* mean,
+                                    const float* invstd, int relu, const double* red, double count, float* dgamma, float* dbeta,
+                                    void* gc, int64_t gc_ps, void* stream) {
+  const BnFin fin{red, count, dgamma, dbeta};
+  return bn_bwd_common(true, dtype, npix, C, ga, ga_ps, ga2, ga2_ps, c, c_ps, scale, shift, mean, invstd, relu, nullptr, nullptr, nullptr, gc, gc_ps, stream, &fin);
+}
+extern "C" int ubr_block_tail_bwd_apply_fin(int dtype, int64_t npix, int C, const void* go, int64_t go_ps, const void* go2, int64_t go2_ps,
+                                            const uint8_t* relu_mask, const void* c2, int64_t c2_ps,
+                                            const float* scale2, const float* shift2, const float* mean2, const float* invstd2,
+                                            const double* red2, float* dgamma2, float* dbeta2,
+                                            const void* cb, int64_t cb_ps, const float* scale_b, const float* mean_b, const float* invstd_b,
+                                            const double* red_b, float* dgamma_b, float* dbeta_b, double count,
+                                            void* g_c2, int64_t g_c2_ps, void* g_sc, int64_t g_sc_ps, void* stream) {
+  UBR_CHECK(relu_mask != nullptr, "ubr_block_tail_bwd_apply_fin: null mask");
+  const TailFin fin{red2, red_b, count, dgamma2, dbeta2, dgamma_b, dbeta_b};
+  return tail_bwd_common(true, dtype, npix, C, go, go_ps, go2, go2_ps, nullptr, 0, c2, c2_ps, scale2, shift2, mean2, invstd2,
+                         nullptr, nullptr, cb, cb_ps, scale_b, mean_b, invstd_b, nullptr, nullptr, nullptr, nullptr,
+                         g_c2, g_c2_ps, g_sc, g_sc_ps, stream, relu_mask, &fin);
 }
 
 extern "C" int ubr_channel_sum(int dtype, int64_t npix, int C, const void* g, int64_t g_ps, double* red, void* stream) {

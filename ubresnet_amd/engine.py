@@ -34,6 +34,9 @@ import os as _os
 # UBR_INFER_FOLD=0: eval forward on the training schedule (BatchNorm applied on load, separate block tails) -- for A/B tests
 _INFER_FOLD = _os.environ.get("UBR_INFER_FOLD", "1") != "0"
 _RELU_MASK = _os.environ.get("UBR_RELU_MASK", "1") != "0"      # block tails keep their final ReLU's mask as bits for the backward
+# BatchNorm-backward finalize fused into the apply pass (every workgroup re-sums the reduce pass's stripes) up to this many
+# channels; wider layers keep the separate ubr_bn_bwd_finalize launch (the re-summation grows with C, the launch does not)
+_FIN_MAX_C = int(_os.environ.get("UBR_FIN_MAX_C", "64"))
 
 
 def _phase(t, ry, rx):
@@ -397,10 +400,14 @@ class Engine:
         """backward through a = relu(bn(c)) (or bn only): returns g_c; writes dgamma/dbeta"""
         red = self._red(2 * site.C, c.device)
         ops.bn_bwd_reduce(ga, ga2, c, site.scale, site.shift, site.mean, site.invstd, relu, red)
+        gc = self._new(c.shape, dtype=c.dtype, device=c.device)
+        if site.C <= _FIN_MAX_C:
+            ops.bn_bwd_apply_fin(ga, ga2, c, site.scale, site.shift, site.mean, site.invstd, relu, red, cnt,
+                                 G(site.mod.weight), G(site.mod.bias), gc)
+            return gc
         k = self._new(2 * site.C, dtype=torch.float32, device=c.device)
         k1, k2 = k[:site.C], k[site.C:]
         ops.bn_bwd_finalize(red, cnt, site.C, G(site.mod.weight), G(site.mod.bias), False, k1, k2)
-        gc = self._new(c.shape, dtype=c.dtype, device=c.device)
         ops.bn_bwd_apply(ga, ga2, c, site.scale, site.shift, site.mean, site.invstd, relu, k1, k2, gc)
         return gc
 
@@ -440,15 +447,20 @@ class Engine:
         mask = getattr(rec, "mask", None)
         ops.block_tail_bwd_reduce(go, go2, out, c2, bn2.scale, bn2.shift, bn2.mean, bn2.invstd,
                                   cb, bnb.mean if byp else None, bnb.invstd if byp else None, red2, redb, relu_mask=mask)
-        k = self._new(4 * Cout, dtype=torch.float32, device=dev)
-        ops.bn_bwd_finalize(red2, cnt, Cout, G(blk.bn2.weight), G(blk.bn2.bias), False, k[:Cout], k[Cout:2 * Cout])
-        if byp:
-            ops.bn_bwd_finalize(redb, cnt, Cout, G(blk.bnpass.weight), G(blk.bnpass.bias), False, k[2 * Cout:3 * Cout], k[3 * Cout:])
         g_c2 = self._new(c2.shape, dtype=dt, device=dev)
         g_sc = self._new(c2.shape, dtype=dt, device=dev)
-        ops.block_tail_bwd_apply(go, go2, out, c2, bn2.scale, bn2.shift, bn2.mean, bn2.invstd, k[:Cout], k[Cout:2 * Cout],
-                                 cb, bnb.scale if byp else None, bnb.mean if byp else None, bnb.invstd if byp else None,
-                                 k[2 * Cout:3 * Cout] if byp else None, k[3 * Cout:] if byp else None, g_c2, g_sc, relu_mask=mask)
+        if mask is not None and Cout <= _FIN_MAX_C:
+            ops.block_tail_bwd_apply_fin(go, go2, mask, c2, bn2.scale, bn2.shift, bn2.mean, bn2.invstd, red2, G(blk.bn2.weight), G(blk.bn2.bias),
+                                         cb, bnb.scale if byp else None, bnb.mean if byp else None, bnb.invstd if byp else None,
+                                         redb, G(blk.bnpass.weight) if byp else None, G(blk.bnpass.bias) if byp else None, cnt, g_c2, g_sc)
+        else:
+            k = self._new(4 * Cout, dtype=torch.float32, device=dev)
+            ops.bn_bwd_finalize(red2, cnt, Cout, G(blk.bn2.weight), G(blk.bn2.bias), False, k[:Cout], k[Cout:2 * Cout])
+            if byp:
+                ops.bn_bwd_finalize(redb, cnt, Cout, G(blk.bnpass.weight), G(blk.bnpass.bias), False, k[2 * Cout:3 * Cout], k[3 * Cout:])
+            ops.block_tail_bwd_apply(go, go2, out, c2, bn2.scale, bn2.shift, bn2.mean, bn2.invstd, k[:Cout], k[Cout:2 * Cout],
+                                     cb, bnb.scale if byp else None, bnb.mean if byp else None, bnb.invstd if byp else None,
+                                     k[2 * Cout:3 * Cout] if byp else None, k[3 * Cout:] if byp else None, g_c2, g_sc, relu_mask=mask)
         # conv2: weight grad (input = relu(bn1(c1)) re-formed on load) and data grad
         kk = 9
         self._wg(c1, g_c2, T3, G(blk.conv2.weight), Cout * kk, kk, Cout, Cout, self.wws, xf=self.relu_affine(bn1))

@@ -417,6 +417,16 @@ def bn_bwd_apply(ga, ga2, c, scale, shift, mean, invstd, relu, k1, k2, gc):
                                      k1.data_ptr(), k2.data_ptr(), gc.data_ptr(), _ps(gc), L.stream_ptr()), "bn_bwd_apply")
 
 
+@_timed("bn_bwd_apply")
+def bn_bwd_apply_fin(ga, ga2, c, scale, shift, mean, invstd, relu, red, count, dgamma, dbeta, gc):
+    """apply pass with the finalize fused: k1 / k2 are formed from `red` inside the kernel, workgroup 0 writes dgamma / dbeta"""
+    L.check(L.lib().ubr_bn_bwd_apply_fin(L.dtype_id(c.dtype), _npix(c), c.shape[3], ga.data_ptr(), _ps(ga),
+                                         L.ptr(ga2), _ps(ga2) if ga2 is not None else 0, c.data_ptr(), _ps(c),
+                                         scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), 1 if relu else 0,
+                                         red.data_ptr(), float(count), L.ptr(dgamma), L.ptr(dbeta), gc.data_ptr(), _ps(gc), L.stream_ptr()),
+            "bn_bwd_apply_fin")
+
+
 # ------------------------------------------------------------------------------------------
 # BasicBlock tail
 # ------------------------------------------------------------------------------------------
@@ -456,6 +466,18 @@ def block_tail_bwd_apply(go, go2, out, c2, scale2, shift2, mean2, invstd2, k1_2,
         L.check(L.lib().ubr_block_tail_bwd_apply(*head, out.data_ptr(), _ps(out), *rest), "block_tail_bwd_apply")
     else:
         L.check(L.lib().ubr_block_tail_bwd_apply_masked(*head, relu_mask.data_ptr(), *rest), "block_tail_bwd_apply_masked")
+
+
+@_timed("block_tail_bwd_apply")
+def block_tail_bwd_apply_fin(go, go2, relu_mask, c2, scale2, shift2, mean2, invstd2, red2, dgamma2, dbeta2,
+                             cb, scale_b, mean_b, invstd_b, red_b, dgamma_b, dbeta_b, count, g_c2, g_sc):
+    """masked apply pass with both finalizes fused; g_sc may be None on an identity block (skip gradient re-formed by the consumer)"""
+    L.check(L.lib().ubr_block_tail_bwd_apply_fin(
+        L.dtype_id(c2.dtype), _npix(c2), c2.shape[3], go.data_ptr(), _ps(go), L.ptr(go2), _ps(go2) if go2 is not None else 0,
+        relu_mask.data_ptr(), c2.data_ptr(), _ps(c2), scale2.data_ptr(), shift2.data_ptr(), mean2.data_ptr(), invstd2.data_ptr(),
+        red2.data_ptr(), L.ptr(dgamma2), L.ptr(dbeta2),
+        L.ptr(cb), _ps(cb) if cb is not None else 0, L.ptr(scale_b), L.ptr(mean_b), L.ptr(invstd_b), L.ptr(red_b), L.ptr(dgamma_b), L.ptr(dbeta_b),
+        float(count), g_c2.data_ptr(), _ps(g_c2), L.ptr(g_sc), _ps(g_sc) if g_sc is not None else 0, L.stream_ptr()), "block_tail_bwd_apply_fin")
 
 
 # ------------------------------------------------------------------------------------------
