@@ -12,6 +12,7 @@ reference's in-place residual add (models/common_layers.py:52,54) is differentia
 
 Usage:  python tests/golden/make_golden.py            # every fixture
         python tests/golden/make_golden.py --only norm   # only the normalised-eval (deployment) fixtures
+        python tests/golden/make_golden.py --only aspp   # only the round-3 ASPP_ResNet / inplanes=32 fixtures
 """
 import hashlib
 import os
@@ -142,12 +143,86 @@ def norm_fixtures(ub):
         print("norm fixture", tag, "absmax logp %.3f" % out.abs().max().item(), "class counts", np.bincount(am.reshape(-1), minlength=4))
 
 
+def aspp_ip32_fixtures(ub, aspp, crit):
+    """Round 3: (a) BASELINE configs[3] at its real size -- the reference ASPP_ResNet (models/ASPP_ResNet.py:291,416-523) on a
+    1 x 3 x 512 x 832 crop, eval forward and one train step, stored as a summary (sampled log-probabilities, class maps' hashes
+    and counts, loss, every gradient tensor's norm and 16 samples); (b) a normalised-eval ASPP fixture (running statistics
+    calibrated by the reference in train mode, then its eval output on a 1 x 3 x 64 x 96 crop, full tensor); (c) the
+    inplanes=32 U-ResNet of training/train_ubresnet2018_wlarcv2.py:88 -- one train step at 1 x 1 x 64 x 64."""
+    sda = O.seeded_state_dict(O.aspp_resnet_schema(3, 3, 16), 44)
+    # (a)
+    x, lab, wgt = synthetic.make_batch(1, 512, 832, 1700, planes=3)
+    m = aspp.ASPP_ResNet(num_classes=3, in_channels=3, inplanes=16, showsizes=False)
+    m.load_state_dict(sda)
+    m.eval()
+    with torch.no_grad():
+        out = m.forward(torch.from_numpy(x))
+    am = out.max(1)[1].numpy().astype(np.uint8)
+    top2 = torch.topk(out, 2, dim=1)[0]
+    margin = (top2[:, 0] - top2[:, 1]).numpy()
+    idx = sample_indices(out.numel(), 4096, 17)
+    m = make_differentiable(aspp.ASPP_ResNet(num_classes=3, in_channels=3, inplanes=16, showsizes=False))
+    m.load_state_dict(sda)
+    out_tr, loss = run_train_step(m, crit, x, lab, wgt)
+    names, norms, samples = grad_summary(m)
+    am_tr = out_tr.argmax(1).astype(np.uint8)
+    t2 = np.sort(out_tr, axis=1)
+    margin_tr = t2[:, -1] - t2[:, -2]
+    np.savez_compressed(
+        os.path.join(HERE, "aspp_ip16_1x3x512x832_summary.npz"),
+        argmax_sha256_eval=np.array(hashlib.sha256(am.tobytes()).hexdigest()), class_counts_eval=np.bincount(am.reshape(-1), minlength=3),
+        low_margin_idx_eval=np.nonzero(margin.reshape(-1) < 1e-3 * np.maximum(1.0, np.abs(out.numpy()).max(1).reshape(-1)))[0].astype(np.int64),
+        sample_idx=idx, sample_logp_eval=out.numpy().reshape(-1)[idx], sample_logp_train=out_tr.reshape(-1)[idx],
+        absmax_eval=np.float32(out.abs().max().item()), absmax_train=np.float32(np.abs(out_tr).max()),
+        argmax_sha256_train=np.array(hashlib.sha256(am_tr.tobytes()).hexdigest()), class_counts_train=np.bincount(am_tr.reshape(-1), minlength=3),
+        argmax_train=np.packbits(am_tr.reshape(-1) == 0), argmax_train1=np.packbits(am_tr.reshape(-1) == 1),
+        low_margin_idx_train=np.nonzero(margin_tr.reshape(-1) < 1e-3)[0].astype(np.int64),
+        loss=np.float64(loss), grad_names=np.array(names), grad_norms=norms, **{"gs__" + k: v for k, v in samples.items()},
+        meta=np.array([1, 3, 512, 832, 1700, 44]))
+    print("aspp 512x832 summary: loss", loss, "eval counts", np.bincount(am.reshape(-1), minlength=3), "absmax eval %.3g train %.3g" % (out.abs().max().item(), np.abs(out_tr).max()))
+    # (b)
+    bn_keys = [k for k in sda if k.endswith("running_mean") or k.endswith("running_var")]
+    m = aspp.ASPP_ResNet(num_classes=3, in_channels=3, inplanes=16, showsizes=False)
+    m.load_state_dict(sda)
+    cal = [synthetic.make_batch(2, 64, 96, 1800 + 10 * i, planes=3)[0] for i in range(2)]
+    calibrate_running_stats(m, cal)
+    after = m.state_dict()
+    x = synthetic.make_batch(1, 64, 96, 1300, planes=3)[0]
+    with torch.no_grad():
+        out = m.forward(torch.from_numpy(x))
+    stats = np.concatenate([after[k].numpy().reshape(-1) for k in bn_keys]).astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, "aspp_ip16_norm_1x3x64x96.npz"), logp_eval=out.numpy().astype(np.float32), bn_keys=np.array(bn_keys),
+                        bn_stats=stats, absmax=np.float32(out.abs().max().item()), meta=np.array([1, 3, 64, 96, 1300, 44]))
+    print("aspp norm fixture: absmax logp %.3f" % out.abs().max().item())
+    # (c)
+    sd32 = O.seeded_state_dict(O.uresnet_schema(3, 1, 32, 16), 45)
+    x, lab, wgt = synthetic.make_batch(1, 64, 64, 1900)
+    m = ub.UResNet(num_classes=3, input_channels=1, inplanes=32)
+    m.load_state_dict(sd32)
+    m.eval()
+    with torch.no_grad():
+        out_eval = m.forward(torch.from_numpy(x)).numpy()
+    m = make_differentiable(ub.UResNet(num_classes=3, input_channels=1, inplanes=32))
+    m.load_state_dict(sd32)
+    out_train, loss = run_train_step(m, crit, x, lab, wgt)
+    names, norms, samples = grad_summary(m)
+    np.savez_compressed(os.path.join(HERE, "uresnet_ip32_1x1x64x64.npz"), logp_eval=out_eval.astype(np.float32), logp_train=out_train.astype(np.float32),
+                        loss=np.float64(loss), grad_names=np.array(names), grad_norms=norms, **{"gs__" + k: v for k, v in samples.items()},
+                        meta=np.array([1, 1, 64, 64, 1900, 45]))
+    print("uresnet ip32 1x1x64x64: loss", loss)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     ub, aspp, pl, cl = import_reference()
     if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "norm":
         norm_fixtures(ub)
+        return
+    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "aspp":
+        crit = pl.PixelWiseNLLLoss()
+        crit.size_average = True   # shim 1
+        aspp_ip32_fixtures(ub, aspp, crit)
         return
 
     # ---------------- schema check: our key order/shape == reference state_dict -------------
@@ -291,6 +366,7 @@ def main():
         meta=np.array([2, 1, 512, 512, 1000, 42]))
     print("512 summary loss", loss, "counts", np.bincount(am.reshape(-1), minlength=3))
     norm_fixtures(ub)
+    aspp_ip32_fixtures(ub, aspp, crit)
 
 
 if __name__ == "__main__":

@@ -92,16 +92,18 @@ CONV_CASES = [
     (1, 32, 64, 16, 16, 7, 1, 1, True, True, True, True, 0),
     (1, 32, 64, 16, 16, 7, 1, 1, True, True, True, True, 2),
     (2, 16, 32, 16, 12, 7, 1, 1, False, False, True, False, 0),
-    # conv_wide_kernel tiles (hint 101..106): 128- and 64-cout workgroup tiles, waves laid out WP x WN
+    # conv_pc_kernel (producer / consumer waves, persistent over (cout tile, pixel tile) units): tiles 101..104 = 8x32, 4x32, 16x16, 8x16 px
     (1, 16, 32, 64, 128, 3, 1, 1, True, False, True, False, 101),
     (1, 8, 32, 128, 128, 3, 1, 1, False, True, True, True, 102),
     (1, 32, 32, 64, 64, 3, 1, 1, True, False, True, False, 103),
     (2, 16, 16, 128, 128, 3, 1, 1, False, False, True, True, 104),
-    (1, 8, 16, 64, 128, 3, 1, 1, True, True, False, False, 105),
-    (1, 16, 16, 32, 64, 3, 1, 1, False, True, True, False, 106),
-    (1, 12, 40, 64, 128, 3, 1, 1, True, False, True, False, 102),    # ragged edges
-    (2, 20, 24, 96, 192, 3, 1, 1, False, False, True, False, 0),      # auto choice, Cout multiple of 64 only
-    (1, 16, 32, 64, 128, 1, 1, 1, False, False, True, False, 101),    # 1x1
+    (1, 8, 16, 64, 128, 3, 1, 1, True, True, False, False, 104),
+    (1, 16, 16, 32, 64, 3, 1, 1, False, True, True, False, 103),      # a single cin block
+    (1, 12, 40, 64, 128, 3, 1, 1, True, False, True, False, 101),    # ragged edges
+    (2, 20, 24, 96, 192, 3, 1, 1, False, False, True, False, 0),      # auto choice: three cout tiles, 16-pixel-wide tiles
+    (1, 16, 32, 64, 128, 1, 1, 1, False, False, True, False, 101),    # 1x1: one K-step per block
+    (3, 128, 128, 64, 128, 3, 1, 1, True, True, True, True, 0),       # 384 units on <= 256 workgroups: units of both cout tiles per workgroup
+    (2, 32, 64, 256, 64, 3, 1, 1, True, False, True, False, 0),       # eight cin blocks
 ]
 
 
@@ -143,6 +145,33 @@ def test_conv_forward(case, dt):
         rs, rss = ref.sum(dim=(0, 2, 3)).double(), (ref.double() ** 2).sum(dim=(0, 2, 3))
         assert (s[:Cout] - rs).abs().max().item() <= tol(dt) * n * max(ref.abs().max().item(), 1e-6)
         assert (s[Cout:] - rss).abs().max().item() <= 2 * tol(dt) * rss.max().item() + 1e-6
+
+
+@pytest.mark.parametrize("dt", DTS + [torch.float16])
+@pytest.mark.parametrize("shape", [(2, 32, 64, 128, 128, 101, 4), (1, 16, 16, 256, 64, 104, 5), (3, 64, 64, 64, 128, 102, 4)])
+def test_conv_pc_equals_igemm_bitwise(dt, shape):
+    """conv_pc_kernel keeps conv_igemm_kernel's order of operations (cin blocks, taps, units): bitwise the same output, whichever
+    kernel or tile a launch gets; BatchNorm-on-load, bias, addend and both activations in the epilogue."""
+    N, H, W, Cin, Cout, hint_pc, hint_ig = shape
+    x = rnd(dt, gen(N, Cin, H, W, seed=11))
+    w = gen(Cout, Cin, 3, 3, seed=12, scale=(2.0 / (9 * Cin)) ** 0.5)
+    b = gen(Cout, seed=13).to(DEV)
+    sc, sh = gen(Cin, seed=14).abs() + 0.5, gen(Cin, seed=15) * 0.3
+    aff = Affine(lo_zero(Cin), sc.to(DEV), sh.to(DEV), lo_zero(Cin))
+    ad = nhwc(rnd(dt, gen(N, Cout, H, W, seed=16)), dt)
+    wp = ops.pack_weights(w.to(DEV), dt, Cout, Cin, Cin * 9, 9, 9)
+    xd = nhwc(x, dt)
+    outs, sts = [], []
+    for hint in (hint_pc, hint_ig):
+        y = torch.empty((N, H, W, Cout), dtype=dt, device=DEV)
+        st = statbuf(2 * Cout)
+        ops.conv(xd, wp, y, ops.conv_taps(3, 1, 1), Cout, xf=aff, bias=b, addend=ad, stats=st, act=3, tile_hint=hint)
+        torch.cuda.synchronize()
+        outs.append(y)
+        sts.append(slotsum(st, 2 * Cout))
+    assert ops.last_conv_kernel().startswith("conv_igemm_kernel")
+    assert torch.equal(outs[0], outs[1])
+    assert torch.allclose(sts[0], sts[1], rtol=1e-6, atol=1e-6)
 
 
 @pytest.mark.parametrize("dt", DTS + [torch.float16])

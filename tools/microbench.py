@@ -42,6 +42,14 @@ if what.startswith("conv"):
     import atexit
     def _dump():
         st = stamps.cpu().view(-1, 16)
+        if ops.last_conv_kernel().startswith("conv_pc_kernel"):
+            st = st[st[:, 3] > 0].float()
+            if len(st):
+                m = st.median(0).values
+                print("pc stamps (median cycles over %d workgroups, %d cin blocks each): consumer wave 0: MFMA loops %d, epilogues %d, barrier waits %d, total %d | "
+                      "producer wave 4: transform + LDS stores %d, load issue %d, barrier waits %d, waiting for loads %d, total %d"
+                      % (len(st), m[4], m[0], m[1], m[2], m[3], m[8], m[9], m[10], m[11], m[12]))
+            return
         st = st[st[:, 4] > 0]
         if len(st):
             m = st.float().median(0).values

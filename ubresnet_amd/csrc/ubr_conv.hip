@@ -40,6 +40,7 @@ struct ConvK {
   int step_j, step_hy, step_goff, wrap_goff;     // halo walk: advance of (column item, row, byte offset) per 256 items
   int wl_off, halo_off, red_off, xfc_off;        // LDS carve offsets
   int epilogue, act, wide_store, dbg, wlinear, N;
+  int buf_stride, ncot;                          // conv_pc_kernel: bytes between its two LDS buffers; cout tiles of the layer
   int8_t dy[UBR_MAX_TAPS], dx[UBR_MAX_TAPS];
   uint8_t wt[UBR_MAX_TAPS];
   unsigned long long* stamps;                    // diagnostic build (-DUBR_CONV_STAMPS): per-workgroup phase cycle sums
@@ -1012,245 +1013,409 @@ __global__ __launch_bounds__(256, (ROW7 ? 2 : 3)) void conv_thin_kernel(const Th
 }
 
 // ---------------------------------------------------------------------------------------------
-// Wide layers (Cout >= 64, several cin blocks, stride 1): the MFMA-bound half of the network (64^2 ... 16^2 maps).
-// conv_igemm_kernel runs them with a 64-cout tile, 4 waves side by side along the pixels and two workgroups per CU: every
-// MFMA then needs half a fresh 1 KB LDS fragment (8 reads per 16 MFMAs per wave, 8 waves per CU = the LDS read port is
-// saturated whenever both workgroups compute), a barrier pair comes every 72 MFMAs, and each 64-cout tile re-reads the
-// activations.  Here ONE workgroup per CU owns a 128-cout (WN = 2) or 64-cout tile and up to 512 pixels:
-//   * waves are laid out WP x WN; a wave's register tile is FW pixel fragments x NT cout fragments (8 x 4 = 128 accumulator
-//     registers): 12 LDS fragment reads feed 32 MFMAs, 4 waves per CU -> 37 % of the LDS read rate instead of 100 %;
-//   * cin blocks of 4 units: 288 MFMAs per wave between barrier pairs; the next block's halo and weight slab are loaded
-//     into registers (the whole 512-entry file is available at one wave per SIMD) under the current block's MFMAs;
-//   * the activations are read once per 128 output channels.
-// Arithmetic per output element is exactly conv_igemm_kernel's (same order over cin blocks, taps and units), so results do
-// not depend on which kernel or tile a launch gets.
+// Wide layers (Cout a multiple of 64, >= 1 cin block of 4 units, stride 1): the 128^2 ... 16^2 maps.  conv_igemm_kernel walks a
+// cin block as  barrier - registers to LDS (BatchNorm transform) - barrier - next block's loads - MFMA loop,  one phase after the
+// other in every wave; at 32^2 and below a layer has only 256 workgroups, so nothing else on the CU fills the staging phases and
+// the matrix pipe idles ~60 % of a workgroup's life (in-kernel stamps), and at 128^2 (1024 small workgroups
+// of two cin blocks) the exposed prologue / epilogue latencies of each workgroup dominate (53 us for 11 us of HBM traffic).
+//
+// conv_pc_kernel: ONE persistent workgroup of 8 waves per CU.
+//   * waves 4-7 (producers, one per SIMD) stage: buffer loads two blocks ahead into two register sets, BatchNorm transform,
+//     LDS writes into the buffer the consumers are NOT reading;
+//   * waves 0-3 (consumers, one per SIMD) run the MFMA loop of conv_igemm_kernel's 64-cout tile (FW pixel fragments x 4 cout
+//     fragments per wave) out of the other buffer, and a tile's epilogue (bias / activation / addend / statistics / stores);
+//   * one s_barrier per cin block (two LDS buffers of halo + weight slab), and the block stream runs ACROSS tiles: a workgroup
+//     walks (cout tile, pixel tile) units with a stride of the grid, so the next tile's first block is staged under the current
+//     tile's last MFMA loop and epilogue.
+// Arithmetic per output element is conv_igemm_kernel's (same order over cin blocks, taps and units): results do not depend on
+// which kernel a launch gets.
 // ---------------------------------------------------------------------------------------------
-__host__ __device__ constexpr int wide_hslots(int fw, int twf, int wn) { return (((4 / wn) * fw / twf + 2) * (twf * 16 + 2) * 4 + 255) / 256; }
-__host__ __device__ constexpr int wide_wslots(int nt, int wn) { return (36 * nt * 16 * wn + 255) / 256; }
-
-template <typename T, int FW, int NT, int TWF, int WN>
-__global__ __launch_bounds__(256, 1) void conv_wide_kernel(const ConvK k) {
-  constexpr int WP = 4 / WN;
-  constexpr int TN = NT * 16 * WN;
-  constexpr int F = WP * FW;
+template <typename T, int FW, int TWF, int STEPS>
+__global__ __launch_bounds__(512) void conv_pc_kernel(const ConvK k) {
+  constexpr int NT = 4, TN = 64;
+  constexpr int F = 4 * FW;
   constexpr int TH = F / TWF;
   constexpr int TW = TWF * 16;
   constexpr int CPU = ET<T>::CPU;
   constexpr int ESZ = 16 / CPU;
-  constexpr int HS = wide_hslots(FW, TWF, WN), WS = wide_wslots(NT, WN);
-  static_assert(F % TWF == 0 && FW % 2 == 0, "tile shape");
+  constexpr int HS = conv_pipe_hslots(FW, TWF), WS = conv_pipe_wslots(NT);
+  constexpr int kOOR = (int)0x80000000;        // beyond any num_records: the load returns zeros
+  static_assert(F % TWF == 0, "tile shape");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* tbl = reinterpret_cast<int*>(smem);
-  char* wl = smem + k.wl_off;
-  char* halo = smem + k.halo_off;
-  float* red = reinterpret_cast<float*>(smem + k.red_off);
+  int* wsrc = tbl + 4 * k.steps;
+  float* xfc = reinterpret_cast<float*>(smem + k.xfc_off);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, l16 = lane & 15;
-  const int wn = wave % WN, wp = wave / WN;
-  int t = blockIdx.x;
-  const int tx = t % k.tiles_x; t /= k.tiles_x;
-  const int ty = t % k.tiles_y;
-  const int n = t / k.tiles_y;
-  const int n0 = blockIdx.y * TN;
-  const int oy0 = ty * TH, ox0 = tx * TW;
-  const int hy0 = oy0 * k.S + k.iy0 + k.dymin, hx0 = ox0 * k.S + k.ix0 + k.dxmin;
+  const bool producer = wave >= 4;
+  const int ptid = tid & 255;
+  const bool has_xf = k.in_scale != nullptr;
 
-  int* wsrc = tbl + 4 * k.steps;
-  for (int u = tid; u < 4 * k.steps; u += 256) {
+  for (int u = tid; u < 4 * k.steps; u += 512) {
     int off = 0, v = -1;
     if (u < k.nunits) {
-      const int tap = u >> k.lgUPB, cc = u & (k.UPB - 1);
+      const int tap = u >> 2, cc = u & 3;
       off = ((k.dy[tap] - k.dymin) * k.HW + (k.dx[tap] - k.dxmin)) * k.pixb + cc * 16;
-      v = ((int)k.wt[tap] * k.CU + cc) * k.Cout_pad;
+      v = ((int)k.wt[tap] * k.CU + cc) * k.Cout_pad;      // per-unit weight-slab source index (16-byte items, cin block 0, channel 0)
     }
     tbl[u] = off;
     wsrc[u] = v;
   }
+  if (has_xf) {
+    // BatchNorm constants of every input channel, [unit][sub | scale | shift | lo][CPU]
+    for (int ch = tid; ch < k.CU * CPU; ch += 512) {
+      float* o = xfc + (ch / CPU) * 4 * CPU + (ch % CPU);
+      o[0] = k.in_sub[ch]; o[CPU] = k.in_scale[ch]; o[2 * CPU] = k.in_shift[ch]; o[3 * CPU] = k.in_lo[ch];
+    }
+  }
   __syncthreads();
 
-  f32x4 acc[FW][NT];
-#pragma unroll
-  for (int i = 0; i < FW; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  int fragbase[FW];
-#pragma unroll
-  for (int i = 0; i < FW; ++i) {
-    const int f = wp * FW + i;
-    fragbase[i] = (((f / TWF) * k.S) * k.HW + (f % TWF) * 16 * k.S) * k.pixb + l16 * k.S * k.pixb;
-  }
+  const int ntiles = k.tiles_x * k.tiles_y * k.N;
+  const int total = ntiles * k.ncot;
+  const int G = (int)gridDim.x;
+  const int nmine = (int)blockIdx.x < total ? (total - (int)blockIdx.x + G - 1) / G : 0;
+  const int niter = nmine * k.nblk;
 
-  const char* xn = k.x + (long)n * k.x_sn;
-  const int nitems = k.HH * (int)k.rw;
-  const bool has_xf = k.in_scale != nullptr;
-  uint4 hv[HS], wv[WS];
-  unsigned hok = 0u;
-  const int c = tid & (k.UPB - 1);
-  const int hy00 = (int)__umulhi((unsigned)tid, k.rw_magic);
-  const int j00 = tid - hy00 * (int)k.rw;
-  const int nw = 4 * k.steps * TN;
-  auto load_blk = [&](int blk) {
-    const int ch0 = (blk * k.UPB + c) * CPU;
-    const char* xc = xn + (long)ch0 * ESZ;
-    int hy = hy00, j = j00;
-    int goff = (hy0 + hy) * k.x_sy32 + (hx0 + (j >> k.lgUPB)) * k.x_sx32;
-    hok = 0u;
-#pragma unroll
-    for (int u = 0; u < HS; ++u) {
-      const int iy = hy0 + hy, ix = hx0 + (j >> k.lgUPB);
-      const bool ok = (tid + u * 256 < nitems) && (unsigned)iy < (unsigned)k.H && (unsigned)ix < (unsigned)k.W;
-      hv[u] = make_uint4(0u, 0u, 0u, 0u);
-      if (ok) { hv[u] = ldg16(xc + goff); hok |= 1u << u; }
-      j += k.step_j; hy += k.step_hy; goff += k.step_goff;
-      if (j >= (int)k.rw) { j -= (int)k.rw; hy += 1; goff += k.wrap_goff; }
-    }
-    const int boff = blk * k.UPB * k.Cout_pad + n0;
-#pragma unroll
-    for (int u = 0; u < WS; ++u) {
-      const int i = tid + u * 256;
-      wv[u] = make_uint4(0u, 0u, 0u, 0u);
-      if (i < nw) {
-        const int src = wsrc[i / TN];
-        if (src >= 0) wv[u] = ldg16(k.w + ((long)(src + boff + (i % TN))) * 16);
-      }
-    }
-  };
-  auto store_blk = [&](int blk) {
-    const int ch0 = (blk * k.UPB + c) * CPU;
-    float xsub[CPU], xsc[CPU], xsh[CPU], xlo[CPU];
-    if (has_xf) {
-#pragma unroll
-      for (int e = 0; e < CPU; ++e) { xsub[e] = k.in_sub[ch0 + e]; xsc[e] = k.in_scale[ch0 + e]; xsh[e] = k.in_shift[ch0 + e]; xlo[e] = k.in_lo[ch0 + e]; }
-    }
-#pragma unroll
-    for (int u = 0; u < HS; ++u) {
-      const int i = tid + u * 256;
-      uint4 v = hv[u];
-      if (has_xf && ((hok >> u) & 1u)) {
-        float f[CPU];
-        ET<T>::unpack(v, f);
-        ubr_bnrelu<CPU>(f, xsub, xsc, xsh, xlo);
-        v = ET<T>::pack(f);
-      }
-      if (i < nitems) *reinterpret_cast<uint4*>(halo + (i >> k.lgUPB) * k.pixb + c * 16) = v;
-    }
-#pragma unroll
-    for (int u = 0; u < WS; ++u) {
-      const int i = tid + u * 256;
-      if (i < nw) *reinterpret_cast<uint4*>(wl + (long)i * 16) = wv[u];
-    }
-  };
-  const char* wlw = wl + ((q * TN) + wn * NT * 16 + l16) * 16;       // this lane's weight fragment column, step 0
-  load_blk(0);
-  for (int blk = 0; blk < k.nblk; ++blk) {
-    if (blk) __syncthreads();          // previous block's fragments fully read
-    store_blk(blk);
-    __syncthreads();
-    if (blk + 1 < k.nblk) load_blk(blk + 1);
-    for (int s = 0; s < k.steps; ++s) {
-      const int off = tbl[4 * s + q];
-      uint4 wf[NT];
-#pragma unroll
-      for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const uint4*>(wlw + (s * 4 * TN + j * 16) * 16);
-#pragma unroll
-      for (int i = 0; i < FW; ++i) {
-        const uint4 a = *reinterpret_cast<const uint4*>(halo + fragbase[i] + off);
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = mma_step<T>(acc[i][j], wf[j], a);
-      }
-    }
-  }
-
-  // ---------------------------------- epilogue ----------------------------------
-  float bs[NT][4];
-#pragma unroll
-  for (int j = 0; j < NT; ++j)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int ch = n0 + (wn * NT + j) * 16 + 4 * q + r;
-      bs[j][r] = (k.bias != nullptr && ch < k.Cout) ? k.bias[ch] : 0.f;
-    }
+  // per-channel statistics of the consumers (fp32 partials over this workgroup's tiles of one cout tile, then fp64)
   float s1[NT][4], s2[NT][4];
 #pragma unroll
   for (int j = 0; j < NT; ++j)
 #pragma unroll
     for (int r = 0; r < 4; ++r) { s1[j][r] = 0.f; s2[j][r] = 0.f; }
 
+  if (producer) {
+    // ------------------------------------------------ producers ------------------------------------------------
+    const int c = ptid & 3;
+    const int nit = k.HH * (int)k.rw;                 // halo items of one block
+    const int nw = 4 * k.steps * TN;                  // weight items of one block
+    // slot geometry that does not depend on the unit: (row, column) inside the halo, byte offset relative to the halo origin
+    int h_rc[HS], h_rel[HS];
 #pragma unroll
-  for (int i = 0; i < FW; i += 2) {
-    int oy[2], ox[2];
-    bool valid[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int f = wp * FW + i + h;
-      oy[h] = oy0 + f / TWF; ox[h] = ox0 + (f % TWF) * 16 + l16;
-      valid[h] = (oy[h] < k.OH) && (ox[h] < k.OW);
+    for (int u = 0; u < HS; ++u) {
+      const int it = ptid + u * 256;
+      const int hy = (int)__umulhi((unsigned)it, k.rw_magic);
+      const int hx = (it - hy * (int)k.rw) >> 2;
+      h_rc[u] = it < nit ? ((hy << 16) | hx) : -1;
+      h_rel[u] = hy * k.x_sy32 + hx * k.x_sx32 + c * 16;
     }
+    int w_rel[WS];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int ch = n0 + (wn * NT + j) * 16 + 4 * q;
-      float v[2][4];
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[h][r] = acc[i + h][j][r] + bs[j][r];
-        if (k.act & 1) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[h][r] = fmaxf(v[h][r], 0.f);
-        }
-        if (k.ad != nullptr && valid[h] && ch < k.Cout) {
-          float a4[4];
-          load4<T>(k.ad + (long)n * k.a_sn + (long)oy[h] * k.a_sy + (long)ox[h] * k.a_sx + (long)ch * ESZ, a4);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[h][r] += a4[r];
-        }
-        if (k.act & 2) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[h][r] = fmaxf(v[h][r], 0.f);
-        }
-        if (k.stats != nullptr && valid[h]) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { s1[j][r] += v[h][r]; s2[j][r] += v[h][r] * v[h][r]; }
-        }
+    for (int u = 0; u < WS; ++u) {
+      const int i = ptid + u * 256;
+      int v = kOOR;
+      if (i < nw) {
+        const int src = wsrc[i / TN];
+        if (src >= 0) v = (src + (i % TN)) * 16;
       }
-      char* p0 = k.y + (long)n * k.y_sn + (long)oy[0] * k.y_sy + (long)ox[0] * k.y_sx + (long)ch * ESZ;
-      char* p1 = k.y + (long)n * k.y_sn + (long)oy[1] * k.y_sy + (long)ox[1] * k.y_sx + (long)ch * ESZ;
-      if (k.wide_store) {
-        // (Cout % 8 == 0: a lane's partner quad is in range whenever the lane is; the exchange needs every lane, so it runs
-        // unconditionally and only the store is predicated)
-        store_frag_pair<T>(p0, p1, valid[0] && ch < k.Cout, valid[1] && ch < k.Cout, v[0], v[1], q);
-      } else {
-        if (valid[0] && ch < k.Cout) store4<T>(p0, v[0]);
-        if (valid[1] && ch < k.Cout) store4<T>(p1, v[1]);
-      }
+      w_rel[u] = v;
     }
-  }
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)k.w, 0, 0x7fffffff, 0x00020000);
+    const int x_img = k.H * k.x_sy32;                 // bytes of one image: rows above / below it read as zero
+    const int hfull = nit >> 8, hrem = nit & 255, wfull = nw >> 8, wrem = nw & 255;
+    const int halo_inc = 64 * k.pixb;                 // 256 items = 64 pixels
+    char* const halo_w0 = smem + k.halo_off + (ptid >> 2) * k.pixb + c * 16;
+    char* const wl_w0 = smem + k.wl_off + ptid * 16;
 
-  if (k.stats != nullptr) {
+    // load cursor: the (unit, block) whose loads are issued next
+    int lu = (int)blockIdx.x, lblk = 0;
+    int hoff[HS], woff[WS];
+    unsigned hok_unit = 0u;
+    __amdgpu_buffer_rsrc_t xr = wr;
+    auto issue = [&](ubr_u4 (&hv)[HS], ubr_u4 (&wv)[WS], unsigned& hokm) {
+      if (lblk == 0) {
+        const int u_ = __builtin_amdgcn_readfirstlane(lu);
+        const int ct = u_ / ntiles;
+        int t = u_ - ct * ntiles;
+        const int tx = t % k.tiles_x; t /= k.tiles_x;
+        const int ty = t % k.tiles_y;
+        const int n = t / k.tiles_y;
+        const int hy0 = ty * TH + k.iy0 + k.dymin, hx0 = tx * TW + k.ix0 + k.dxmin;
+        xr = __builtin_amdgcn_make_buffer_rsrc((void*)(k.x + (long)n * k.x_sn), 0, x_img, 0x00020000);
+        const int org = hy0 * k.x_sy32 + hx0 * k.x_sx32;     // negative above the image: the sum wraps out of range
+        hok_unit = 0u;
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+        for (int u = 0; u < HS; ++u) {
+          const int hy = h_rc[u] >> 16, hx = h_rc[u] & 0xffff;
+          const bool okx = h_rc[u] >= 0 && (unsigned)(hx0 + hx) < (unsigned)k.W;
+          hoff[u] = okx ? h_rel[u] + org : kOOR;
+          hok_unit |= (okx && (unsigned)(hy0 + hy) < (unsigned)k.H) ? (1u << u) : 0u;
+        }
+        const int n0b = ct * TN * 16;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float a = wave_quadrow_sum16(s1[j][r]);
-        const float b = wave_quadrow_sum16(s2[j][r]);
-        if (l16 == 0) {
-          red[(wp * TN + (wn * NT + j) * 16 + 4 * q + r) * 2 + 0] = a;
-          red[(wp * TN + (wn * NT + j) * 16 + 4 * q + r) * 2 + 1] = b;
+        for (int u = 0; u < WS; ++u) woff[u] = w_rel[u] == kOOR ? kOOR : w_rel[u] + n0b;
+      }
+      const int sh = lblk * 64, sw = lblk * 4 * k.Cout_pad * 16;
+#pragma unroll
+      for (int u = 0; u < HS; ++u) hv[u] = __builtin_amdgcn_raw_buffer_load_b128(xr, hoff[u], sh, 0);
+#pragma unroll
+      for (int u = 0; u < WS; ++u) wv[u] = __builtin_amdgcn_raw_buffer_load_b128(wr, woff[u], sw, 0);
+      hokm = hok_unit;
+      if (++lblk == k.nblk) { lblk = 0; lu += G; }
+    };
+    // stage cursor: cin block (inside its unit) of the register set that is written to LDS next
+    int sblk = 0;
+    auto stage = [&](const ubr_u4 (&hv)[HS], const ubr_u4 (&wv)[WS], unsigned hokm, int buf) {
+      char* const wl_w = wl_w0 + buf * k.buf_stride;
+      char* const halo_w = halo_w0 + buf * k.buf_stride;
+#pragma unroll
+      for (int u = 0; u < WS; ++u)
+        if (u < wfull || (u == wfull && ptid < wrem)) *reinterpret_cast<ubr_u4*>(wl_w + u * 4096) = wv[u];
+      float xsub[CPU], xsc[CPU], xsh[CPU], xlo[CPU];
+      if (has_xf) {
+        const float4* cp = reinterpret_cast<const float4*>(xfc + (sblk * 4 + c) * 4 * CPU);
+#pragma unroll
+        for (int e = 0; e < CPU; e += 4) {
+          const float4 a = cp[e / 4], b = cp[(CPU + e) / 4], cc = cp[(2 * CPU + e) / 4], d = cp[(3 * CPU + e) / 4];
+          xsub[e] = a.x; xsub[e + 1] = a.y; xsub[e + 2] = a.z; xsub[e + 3] = a.w;
+          xsc[e] = b.x; xsc[e + 1] = b.y; xsc[e + 2] = b.z; xsc[e + 3] = b.w;
+          xsh[e] = cc.x; xsh[e + 1] = cc.y; xsh[e + 2] = cc.z; xsh[e + 3] = cc.w;
+          xlo[e] = d.x; xlo[e + 1] = d.y; xlo[e + 2] = d.z; xlo[e + 3] = d.w;
         }
       }
-    __syncthreads();
-    if (tid < TN) {
-      const int ch = n0 + tid;
-      if (ch < k.Cout) {
-        double a = 0.0, b = 0.0;
 #pragma unroll
-        for (int w = 0; w < WP; ++w) { a += (double)red[(w * TN + tid) * 2]; b += (double)red[(w * TN + tid) * 2 + 1]; }
-        double* st = k.stats + (size_t)(blockIdx.x % UBR_STAT_SLOTS) * 2 * k.Cout;
-        atomicAdd(&st[ch], a);
-        atomicAdd(&st[k.Cout + ch], b);
+      for (int u = 0; u < HS; ++u) {
+        uint4 v = make_uint4(hv[u].x, hv[u].y, hv[u].z, hv[u].w);
+        if (has_xf) {
+          float f[CPU];
+          ET<T>::unpack(v, f);
+          ubr_bnrelu<CPU>(f, xsub, xsc, xsh, xlo);
+          const uint4 t4 = ET<T>::pack(f);
+          const bool ok = (hokm >> u) & 1u;          // padding stays zero
+          v.x = ok ? t4.x : 0u; v.y = ok ? t4.y : 0u; v.z = ok ? t4.z : 0u; v.w = ok ? t4.w : 0u;
+        }
+        if (u < hfull || (u == hfull && ptid < hrem)) *reinterpret_cast<uint4*>(halo_w + u * halo_inc) = v;
       }
+      if (++sblk == k.nblk) sblk = 0;
+    };
+
+    ubr_u4 hvA[HS], wvA[WS], hvB[HS], wvB[WS];
+    unsigned hokA = 0u, hokB = 0u;
+#ifdef UBR_CONV_STAMPS
+    unsigned long long tS = 0, tL = 0, tB = 0, tW = 0, t_ = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_begin = t_;
+#define UBR_PSTAMP(acc_) do { unsigned long long n_ = __builtin_amdgcn_s_memtime(); acc_ += n_ - t_; t_ = n_; } while (0)
+#define UBR_PWAIT(n_) do { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n_) : "memory"); UBR_PSTAMP(tW); } while (0)
+#else
+#define UBR_PSTAMP(acc_) do { } while (0)
+#define UBR_PWAIT(n_) do { } while (0)
+#endif
+    if (niter > 0) issue(hvA, wvA, hokA);
+    if (niter > 1) issue(hvB, wvB, hokB);
+    UBR_PSTAMP(tL);
+    if (niter > 0) stage(hvA, wvA, hokA, 0);
+    UBR_PSTAMP(tS);
+    if (niter > 2) issue(hvA, wvA, hokA);
+    UBR_PSTAMP(tL);
+    __syncthreads();                                   // buffer 0 holds block 0
+    UBR_PSTAMP(tB);
+    for (int i = 0; i < niter; i += 2) {
+      if (i + 1 < niter) {                             // consumers are in block i (buffer 0): block i+1 goes to buffer 1
+        UBR_PWAIT(HS + WS);
+        stage(hvB, wvB, hokB, 1);
+        UBR_PSTAMP(tS);
+        if (i + 3 < niter) issue(hvB, wvB, hokB);
+        UBR_PSTAMP(tL);
+      }
+      __syncthreads();
+      UBR_PSTAMP(tB);
+      if (i + 1 >= niter) break;
+      if (i + 2 < niter) {                             // consumers are in block i+1 (buffer 1): block i+2 goes to buffer 0
+        UBR_PWAIT(HS + WS);
+        stage(hvA, wvA, hokA, 0);
+        UBR_PSTAMP(tS);
+        if (i + 4 < niter) issue(hvA, wvA, hokA);
+        UBR_PSTAMP(tL);
+      }
+      __syncthreads();
+      UBR_PSTAMP(tB);
     }
+#ifdef UBR_CONV_STAMPS
+    if (k.stamps != nullptr && ptid == 0) {
+      unsigned long long* o = k.stamps + (size_t)blockIdx.x * 16;
+      o[8] = tS; o[9] = tL; o[10] = tB; o[11] = tW; o[12] = t_ - t_begin;
+    }
+#endif
+  } else {
+    // ------------------------------------------------ consumers ------------------------------------------------
+    f32x4 acc[FW][NT];
+    int fragbase[FW];
+#pragma unroll
+    for (int i = 0; i < FW; ++i) {
+      const int f = wave * FW + i;
+      const int fr = f / TWF, fc = f % TWF;
+      fragbase[i] = (fr * k.HW + fc * 16) * k.pixb + l16 * k.pixb;
+    }
+    int cu = (int)blockIdx.x, cblk = 0;
+    int stat_n0 = -1;
+    // a wave's per-channel sums: after the quad-row reduction lane (q, l16 == 0) holds channels 4q..4q+3 of each cout fragment;
+    // they are transposed through a wave-private LDS row (no barrier: a wave sees its own LDS writes after lgkmcnt(0)) so that
+    // lane c owns channel c and the wave issues TWO fp64 atomic instructions (64 of them, one lane each, cost ~8 k cycles per flush)
+    float* srow = reinterpret_cast<float*>(smem + k.red_off) + wave * 2 * TN;
+    auto flush_stats = [&](int n0) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float a = wave_quadrow_sum16(s1[j][r]);
+          const float b = wave_quadrow_sum16(s2[j][r]);
+          if (l16 == 0) { srow[j * 16 + 4 * q + r] = a; srow[TN + j * 16 + 4 * q + r] = b; }
+          s1[j][r] = 0.f; s2[j][r] = 0.f;
+        }
+      __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): this wave's LDS writes have landed
+      __builtin_amdgcn_wave_barrier();
+      const float a = srow[lane], b = srow[TN + lane];
+      const int ch = n0 + lane;
+      if (ch < k.Cout) {
+        double* st = k.stats + (size_t)((blockIdx.x * 4 + wave) % UBR_STAT_SLOTS) * 2 * k.Cout;
+        atomicAdd(&st[ch], (double)a);
+        atomicAdd(&st[k.Cout + ch], (double)b);
+      }
+    };
+    // this lane's tap offsets of every K-step (quad q reads cin unit q of the step's tap)
+    int offq[STEPS > 0 ? STEPS : 1];
+    if constexpr (STEPS > 0) {
+#pragma unroll
+      for (int s_ = 0; s_ < STEPS; ++s_) offq[s_] = tbl[4 * s_ + q];
+    }
+    __builtin_amdgcn_s_setprio(2);                     // the matrix pipe's wave wins issue arbitration against the producer on its SIMD
+#ifdef UBR_CONV_STAMPS
+    unsigned long long tC = 0, tE = 0, tB = 0, t_ = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_begin = t_;
+#endif
+    __syncthreads();                                   // buffer 0 holds block 0
+    UBR_PSTAMP(tB);
+    for (int i = 0; i < niter; ++i) {
+      const char* wl = smem + k.wl_off + (i & 1) * k.buf_stride;
+      const char* halo = smem + k.halo_off + (i & 1) * k.buf_stride;
+      if (cblk == 0) {
+#pragma unroll
+        for (int a = 0; a < FW; ++a)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[a][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      // ---- MFMA over (tap, cin unit); the next step's fragments (weights and pixels) are read one step ahead ----
+      if constexpr (STEPS > 0) {
+        uint4 wfc[NT], ac[FW], wfn[NT], an[FW];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wfc[j] = *reinterpret_cast<const uint4*>(wl + ((q * TN) + j * 16 + l16) * 16);
+#pragma unroll
+        for (int i2 = 0; i2 < FW; ++i2) ac[i2] = *reinterpret_cast<const uint4*>(halo + fragbase[i2] + offq[0]);
+#pragma unroll
+        for (int s_ = 0; s_ < STEPS; ++s_) {
+          if (s_ + 1 < STEPS) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) wfn[j] = *reinterpret_cast<const uint4*>(wl + (((4 * (s_ + 1) + q) * TN) + j * 16 + l16) * 16);
+#pragma unroll
+            for (int i2 = 0; i2 < FW; ++i2) an[i2] = *reinterpret_cast<const uint4*>(halo + fragbase[i2] + offq[s_ + 1]);
+          }
+          __builtin_amdgcn_sched_barrier(0);          // keep the next step's reads ahead of this step's MFMAs (the scheduler would sink them to their uses)
+#pragma unroll
+          for (int i2 = 0; i2 < FW; ++i2)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i2][j] = mma_step<T>(acc[i2][j], wfc[j], ac[i2]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (s_ + 1 < STEPS) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) wfc[j] = wfn[j];
+#pragma unroll
+            for (int i2 = 0; i2 < FW; ++i2) ac[i2] = an[i2];
+          }
+        }
+      } else {
+      int off_n = tbl[q];
+      uint4 wf_n[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) wf_n[j] = *reinterpret_cast<const uint4*>(wl + ((q * TN) + j * 16 + l16) * 16);
+      for (int s = 0; s < k.steps; ++s) {
+        const int off = off_n;
+        uint4 wf[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wf[j] = wf_n[j];
+        if (s + 1 < k.steps) {
+          off_n = tbl[4 * (s + 1) + q];
+#pragma unroll
+          for (int j = 0; j < NT; ++j) wf_n[j] = *reinterpret_cast<const uint4*>(wl + (((4 * (s + 1) + q) * TN) + j * 16 + l16) * 16);
+        }
+        uint4 a[FW];
+#pragma unroll
+        for (int i2 = 0; i2 < FW; ++i2) a[i2] = *reinterpret_cast<const uint4*>(halo + fragbase[i2] + off);
+#pragma unroll
+        for (int i2 = 0; i2 < FW; ++i2)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i2][j] = mma_step<T>(acc[i2][j], wf[j], a[i2]);
+      }
+      }
+      UBR_PSTAMP(tC);
+      if (++cblk == k.nblk) {
+        // ---------------------------------- epilogue of this unit ----------------------------------
+        cblk = 0;
+        const int u_ = __builtin_amdgcn_readfirstlane(cu);
+        cu += G;
+        const int ct = u_ / ntiles;
+        int t = u_ - ct * ntiles;
+        const int tx = t % k.tiles_x; t /= k.tiles_x;
+        const int ty = t % k.tiles_y;
+        const int n = t / k.tiles_y;
+        const int n0 = ct * TN, oy0 = ty * TH, ox0 = tx * TW;
+        if (k.stats != nullptr && stat_n0 != n0) {
+          if (stat_n0 >= 0) flush_stats(stat_n0);
+          stat_n0 = n0;
+        }
+        float bs[NT][4];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int ch = n0 + j * 16 + 4 * q + r;
+            bs[j][r] = (k.bias != nullptr && ch < k.Cout) ? k.bias[ch] : 0.f;
+          }
+#pragma unroll
+        for (int i2 = 0; i2 < FW; ++i2) {
+          const int f = wave * FW + i2;
+          const int oy = oy0 + f / TWF, ox = ox0 + (f % TWF) * 16 + l16;
+          const bool valid = (oy < k.OH) && (ox < k.OW);
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const int ch = n0 + j * 16 + 4 * q;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[i2][j][r] + bs[j][r];
+            if (k.act & 1) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (k.ad != nullptr && valid && ch < k.Cout) {
+              float a4[4];
+              load4<T>(k.ad + (long)n * k.a_sn + (long)oy * k.a_sy + (long)ox * k.a_sx + (long)ch * ESZ, a4);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] += a4[r];
+            }
+            if (k.act & 2) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (k.stats != nullptr && valid) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) { s1[j][r] += v[r]; s2[j][r] += v[r] * v[r]; }
+            }
+            if (valid && ch < k.Cout)
+              store4<T>(k.y + (long)n * k.y_sn + (long)oy * k.y_sy + (long)ox * k.y_sx + (long)ch * ESZ, v);
+          }
+        }
+      }
+      UBR_PSTAMP(tE);
+      __syncthreads();
+      UBR_PSTAMP(tB);
+    }
+    if (k.stats != nullptr && stat_n0 >= 0) flush_stats(stat_n0);
+#ifdef UBR_CONV_STAMPS
+    UBR_PSTAMP(tE);
+    if (k.stamps != nullptr && tid == 0) {
+      unsigned long long* o = k.stamps + (size_t)blockIdx.x * 16;
+      o[0] = tC; o[1] = tE; o[2] = tB; o[3] = t_ - t_begin; o[4] = (unsigned long long)niter;
+    }
+#endif
   }
 }
 
@@ -1422,9 +1587,9 @@ int launch_cfg(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
   return launch_one<T, FW, NT, TWF, false>(k, grid, lds, st);
 }
 
-template <typename T, int FW, int NT, int TWF, int WN>
-int launch_wide_one(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
-  auto fn = conv_wide_kernel<T, FW, NT, TWF, WN>;
+template <typename T, int FW, int TWF, int STEPS>
+int launch_pc_steps(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
+  auto fn = conv_pc_kernel<T, FW, TWF, STEPS>;
   if (lds > 64 * 1024) {
     static thread_local size_t maxset = 0;
     if (lds > maxset) {
@@ -1433,29 +1598,35 @@ int launch_wide_one(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
       maxset = lds;
     }
   }
-  ubr_launch(fn, grid, dim3(256), lds, st, k);
+  ubr_launch(fn, grid, dim3(512), lds, st, k);
   UBR_LAUNCH_CHECK("ubr_conv");
   return UBR_OK;
 }
 
+template <typename T, int FW, int TWF>
+int launch_pc_one(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
+  // 3x3 and the 2x2 phases of the transposed convs get a fully unrolled K-step loop; other tap counts the generic one
+  if (k.steps == 9) return launch_pc_steps<T, FW, TWF, 9>(k, grid, lds, st);
+  if (k.steps == 4) return launch_pc_steps<T, FW, TWF, 4>(k, grid, lds, st);
+  return launch_pc_steps<T, FW, TWF, 0>(k, grid, lds, st);
+}
+
 template <typename T>
-int launch_wide(int wi, const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
+int launch_pc(int pi, const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
   g_last_conv_cfg[3] = 3;
-  switch (wi) {
-    case 0: return launch_wide_one<T, 8, 4, 2, 2>(k, grid, lds, st);
-    case 1: return launch_wide_one<T, 4, 4, 2, 2>(k, grid, lds, st);
-    case 2: return launch_wide_one<T, 8, 4, 2, 1>(k, grid, lds, st);
-    case 3: return launch_wide_one<T, 4, 4, 1, 2>(k, grid, lds, st);
-    case 4: return launch_wide_one<T, 2, 4, 1, 2>(k, grid, lds, st);
-    case 5: return launch_wide_one<T, 4, 4, 1, 1>(k, grid, lds, st);
+  switch (pi) {
+    case 0: return launch_pc_one<T, 4, 2>(k, grid, lds, st);
+    case 1: return launch_pc_one<T, 2, 2>(k, grid, lds, st);
+    case 2: return launch_pc_one<T, 4, 1>(k, grid, lds, st);
+    case 3: return launch_pc_one<T, 2, 1>(k, grid, lds, st);
   }
-  ubr_set_error("ubr_conv: bad wide tile %d", wi);
+  ubr_set_error("ubr_conv: bad producer/consumer tile %d", pi);
   return UBR_EINVAL;
 }
 
 template <typename T>
 int launch_T(int cfg, const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
-  if (cfg >= 100) return launch_wide<T>(cfg - 100, k, grid, lds, st);
+  if (cfg >= 100) return launch_pc<T>(cfg - 100, k, grid, lds, st);
   switch (cfg) {
     case 0: return launch_cfg<T, 8, 1, 2>(k, grid, lds, st);
     case 1: return launch_cfg<T, 4, 1, 2>(k, grid, lds, st);
@@ -1472,7 +1643,7 @@ int launch_T(int cfg, const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
   return UBR_EINVAL;
 }
 
-struct Plan { int cfg; size_t lds; int UPB, steps, HH, HW, pixb, wl_off, halo_off, red_off, xfc_off, tiles_x, tiles_y; };
+struct Plan { int cfg; size_t lds; int UPB, steps, HH, HW, pixb, wl_off, halo_off, red_off, xfc_off, tiles_x, tiles_y, pc_buf; };
 
 static bool plan_tile(const ubr_conv_desc* d, int cfg, int TH, int TW, int TN, int dymin, int dymax, int dxmin, int dxmax, Plan* p) {
   if (d->Cout_pad % TN) return false;
@@ -1508,28 +1679,44 @@ static bool plan_for(const ubr_conv_desc* d, int cfg, int dymin, int dymax, int 
   return plan_tile(d, cfg, 4 * c.FW / c.TWF, c.TWF * 16, c.NT * 16, dymin, dymax, dxmin, dxmax, p);
 }
 
-// conv_wide_kernel tiles: {FW, NT, TWF, WN}; id = 100 + index
-struct WideCfg { int FW, NT, TWF, WN; };
-static const WideCfg kWide[] = {
-    {8, 4, 2, 2},   // 100:  8x32 px x 128 ch
-    {4, 4, 2, 2},   // 101:  4x32 px x 128 ch
-    {8, 4, 2, 1},   // 102: 16x32 px x  64 ch
-    {4, 4, 1, 2},   // 103:  8x16 px x 128 ch
-    {2, 4, 1, 2},   // 104:  4x16 px x 128 ch
-    {4, 4, 1, 1},   // 105: 16x16 px x  64 ch
+// conv_pc_kernel tiles: {FW, TWF} (always 64 output channels); id = 100 + index
+struct PcCfg { int FW, TWF; };
+static const PcCfg kPc[] = {
+    {4, 2},   // 100:  8x32 px
+    {2, 2},   // 101:  4x32 px
+    {4, 1},   // 102: 16x16 px
+    {2, 1},   // 103:  8x16 px
 };
-constexpr int kNumWide = sizeof(kWide) / sizeof(kWide[0]);
+constexpr int kNumPc = sizeof(kPc) / sizeof(kPc[0]);
 
-static bool plan_wide(const ubr_conv_desc* d, int wi, int dymin, int dymax, int dxmin, int dxmax, Plan* p) {
-  const WideCfg& c = kWide[wi];
-  const int WP = 4 / c.WN, TH = WP * c.FW / c.TWF, TW = c.TWF * 16, TN = c.NT * 16 * c.WN;
-  if (d->S != 1 || d->epilogue != 0 || d->ntaps > 9) return false;
-  if (!plan_tile(d, 100 + wi, TH, TW, TN, dymin, dymax, dxmin, dxmax, p)) return false;
-  if (p->UPB != 4) return false;
-  if ((long)p->HH * p->HW * 4 > 256L * wide_hslots(c.FW, c.TWF, c.WN)) return false;     // register slots of the block pipeline
-  if (4L * p->steps * TN > 256L * wide_wslots(c.NT, c.WN)) return false;
+static bool plan_pc(const ubr_conv_desc* d, int pi, int dymin, int dymax, int dxmin, int dxmax, Plan* p) {
+  const PcCfg& c = kPc[pi];
+  const int TH = 4 * c.FW / c.TWF, TW = c.TWF * 16, TN = 64;
+  const int cpu = ubr_cpu(d->dtype);
+  if (d->S != 1 || d->epilogue != 0 || d->ntaps > 9 || d->Cout_pad % TN || d->Cin % (4 * cpu)) return false;
   if (c.TWF == 2 && d->OW < 32) return false;
-  return true;
+  const int steps = d->ntaps;                                   // 4-unit cin blocks: one K-step per tap
+  const int HH = TH + (dymax - dymin), HW = TW + (dxmax - dxmin);
+  // 96 bytes per halo pixel: conflict-free against the ds_read_b128 lane groups (conv_pixb: the 80-byte stride of the other kernels
+  // is a 2-way conflict on every pixel-fragment read, and in this kernel the LDS array, shared by four reading and four writing
+  // waves, is the busiest unit)
+  static const int pixb = [] { const char* e = getenv("UBR_PC_PIXB"); return e ? atoi(e) : 96; }();
+  if ((long)HH * HW * 4 > 256L * conv_pipe_hslots(c.FW, c.TWF)) return false;      // register slots of the producers
+  if (4L * steps * TN > 256L * conv_pipe_wslots(4)) return false;
+  size_t off = ((size_t)2 * 16 * steps + 15) & ~(size_t)15;     // tap-offset table + weight-source table
+  p->wl_off = (int)off;
+  const size_t wlb = (size_t)4 * steps * TN * 16;
+  p->halo_off = (int)(off + wlb);
+  const size_t buf = (wlb + (size_t)HH * HW * pixb + 15) & ~(size_t)15;
+  off += 2 * buf;
+  p->pc_buf = (int)buf;
+  p->red_off = (int)off; off += (size_t)4 * 2 * TN * sizeof(float);        // one statistics row per consumer wave
+  p->xfc_off = (int)off;
+  if (d->xf.scale != nullptr) off += (size_t)d->Cin * 4 * sizeof(float);
+  p->cfg = 100 + pi; p->lds = off; p->UPB = 4; p->steps = steps; p->HH = HH; p->HW = HW; p->pixb = pixb;
+  p->tiles_x = ubr_cdiv(d->OW, TW); p->tiles_y = ubr_cdiv(d->OH, TH);
+  if ((size_t)HH * HW * 4 >= 60000) return false;
+  return off <= 160 * 1024;
 }
 
 }  // namespace
@@ -1607,10 +1794,10 @@ extern "C" int ubr_conv(const ubr_conv_desc* d, void* stream) {
                        (d->y.sy * esz) % 16 == 0 && (d->y.sn * esz) % 16 == 0;
   // ---- choose a tile configuration ----
   Plan best{}; bool have = false;
-  if (d->tile_hint > 100) {        // 101.. = conv_wide_kernel tiles (tests)
-    UBR_CHECK(d->tile_hint <= 100 + kNumWide, "ubr_conv: tile_hint %d out of range", d->tile_hint);
-    have = plan_wide(d, d->tile_hint - 101, dymin, dymax, dxmin, dxmax, &best);
-    UBR_CHECK(have, "ubr_conv: wide tile_hint %d does not fit this shape", d->tile_hint);
+  if (d->tile_hint > 100) {        // 101.. = conv_pc_kernel tiles (tests)
+    UBR_CHECK(d->tile_hint <= 100 + kNumPc, "ubr_conv: tile_hint %d out of range", d->tile_hint);
+    have = plan_pc(d, d->tile_hint - 101, dymin, dymax, dxmin, dxmax, &best);
+    UBR_CHECK(have, "ubr_conv: producer/consumer tile_hint %d does not fit this shape", d->tile_hint);
   } else if (d->tile_hint > 0) {
     UBR_CHECK(d->tile_hint <= kNumCfgs, "ubr_conv: tile_hint %d out of range", d->tile_hint);
     have = plan_for(d, d->tile_hint - 1, dymin, dymax, dxmin, dxmax, &best);
@@ -1619,24 +1806,26 @@ extern "C" int ubr_conv(const ubr_conv_desc* d, void* stream) {
     // widest channel tile that divides Cout_pad; then the largest pixel tile that still yields
     // >= 512 workgroups (2 per CU), else the smallest tile.
     const int order_by_nt[3][4] = {{3, 4, 5, -1}, {2, 6, 8, -1}, {0, 1, 7, 9}};
-    // wide layers (Cout a multiple of 64, stride 1, <= 9 taps, 4-unit cin blocks): the largest conv_wide_kernel tile that still
-    // yields one workgroup per CU; 128-cout tiles before 64-cout ones
+    // conv_pc_kernel (Cout a multiple of 64, Cin a multiple of 4 units, stride 1, 4..9 taps) takes the layers where it beats
+    // conv_igemm_kernel INSIDE a train step: at most two cin blocks (a workgroup of the block pipeline has no second block to
+    // overlap anything with: 32 -> 64 at 256^2 95 vs 152 us, 64 -> 128 at 128^2 66 vs 89 us), and 16 x 16 maps (512 -> 512: 45 vs
+    // 52 us).  On the 4- and 8-block layers at 64^2 / 32^2 it is level alone and SLOWER in the step (45 vs 36 us): its 128-147 KB of
+    // LDS do not fit on a CU beside a weight-gradient workgroup of the side stream (79 KB), so it waits for free CUs.
+    // The rule depends on the layer, never on the batch; both kernels compute the same bits.
     {
-      static const bool wide_on = [] { const char* e = getenv("UBR_CONV_WIDE"); return e && atoi(e) != 0; }();   // off by default: see DESIGN.md section 8 (measured)
-      static const int wide_min = [] { const char* e = getenv("UBR_CONV_WIDE_MINWG"); return e ? atoi(e) : 256; }();
-      if (wide_on && d->Cout_pad % 64 == 0) {
+      static const int pc_mode = [] { const char* e = getenv("UBR_CONV_PC"); return e ? atoi(e) : 1; }();   // 0 off, 1 selective, 2 every eligible layer
+      const int nblk_pc = d->Cin / (4 * cpu);
+      const bool pick = pc_mode == 2 || (pc_mode == 1 && (nblk_pc <= 2 || (long)d->OH * d->OW <= 256) && !(d->Cin == d->Cout_pad && nblk_pc == 2));
+      if (pick && d->Cout_pad % 64 == 0 && d->ntaps >= 4) {
         Plan cand{}; bool any = false;
-        const int order128[] = {0, 1, 3, 4}, order64[] = {2, 5};
-        const bool c128 = d->Cout_pad % 128 == 0;
-        const int* ord = c128 ? order128 : order64;
-        const int nord = c128 ? 4 : 2;
-        for (int i = 0; i < nord && !have; ++i) {
+        const int wide[] = {0, 1}, narrow[] = {2, 3};
+        const int* ord = d->OW >= 32 ? wide : narrow;
+        for (int i = 0; i < 2 && !have; ++i) {
           Plan p{};
-          if (!plan_wide(d, ord[i], dymin, dymax, dxmin, dxmax, &p)) continue;
-          const WideCfg& c = kWide[ord[i]];
-          const long wgs = (long)p.tiles_x * p.tiles_y * d->N * (d->Cout_pad / (c.NT * 16 * c.WN));
+          if (!plan_pc(d, ord[i], dymin, dymax, dxmin, dxmax, &p)) continue;
+          const long units = (long)p.tiles_x * p.tiles_y * d->N * (d->Cout_pad / 64);
           cand = p; any = true;
-          if (wgs >= wide_min) { best = p; have = true; }
+          if (units >= 256) { best = p; have = true; }
         }
         if (!have && any) { best = cand; have = true; }
       }
@@ -1706,10 +1895,19 @@ extern "C" int ubr_conv(const ubr_conv_desc* d, void* stream) {
 
   TileCfg c{};
   int tn;
-  if (best.cfg >= 100) { const WideCfg& w = kWide[best.cfg - 100]; c = TileCfg{w.FW, w.NT * w.WN, w.TWF}; tn = w.NT * 16 * w.WN; }
+  if (best.cfg >= 100) { const PcCfg& w = kPc[best.cfg - 100]; c = TileCfg{w.FW, 4, w.TWF}; tn = 64; }
   else { c = kCfgs[best.cfg]; tn = c.NT * 16; }
   g_last_conv_cfg[0] = c.FW; g_last_conv_cfg[1] = c.NT; g_last_conv_cfg[2] = c.TWF;
   dim3 grid((unsigned)(best.tiles_x * best.tiles_y * d->N), (unsigned)(d->Cout_pad / tn));
+  if (best.cfg >= 100) {
+    // persistent: one workgroup of 8 waves per CU walks the (cout tile, pixel tile) units
+    static const int ncu = [] { hipDeviceProp_t pr; int dev = 0; return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }();
+    k.ncot = d->Cout_pad / 64;
+    k.buf_stride = best.pc_buf;
+    const long units = (long)grid.x * k.ncot;
+    UBR_CHECK(units < (1L << 30), "ubr_conv: too many tiles");
+    grid = dim3((unsigned)(units < ncu ? units : ncu), 1);
+  }
   hipStream_t st = (hipStream_t)stream;
   {
     static const bool dbg = [] { const char* e = getenv("UBR_CONV_DEBUG"); return e && atoi(e) != 0; }();
@@ -1727,7 +1925,7 @@ extern "C" int ubr_conv(const ubr_conv_desc* d, void* stream) {
       default: rc = launch_T<f16_t>(best.cfg, k, grid, best.lds, st); break;
     }
     if (g_last_conv_name[0] == 0) {     // (the thin path names itself)
-      if (best.cfg >= 100) { const WideCfg& w = kWide[best.cfg - 100]; snprintf(g_last_conv_name, sizeof(g_last_conv_name), "conv_wide_kernel<%s, %d, %d, %d, %d>", tn, w.FW, w.NT, w.TWF, w.WN); }
+      if (best.cfg >= 100) { const PcCfg& w = kPc[best.cfg - 100]; snprintf(g_last_conv_name, sizeof(g_last_conv_name), "conv_pc_kernel<%s, %d, %d, %d>", tn, w.FW, w.TWF, (best.steps == 9 || best.steps == 4) ? best.steps : 0); }
       else snprintf(g_last_conv_name, sizeof(g_last_conv_name), "conv_igemm_kernel<%s, %d, %d, %d, %s>", tn, c.FW, c.NT, c.TWF, g_last_conv_cfg[3] == 1 ? "true" : "false");
     }
     return rc;

@@ -65,7 +65,10 @@ __device__ __forceinline__ uint4 sc_frag32(const char* p0, int pstride) {
 // The wide 9-tap tile (N-split, MA = 2) walks 8-row pixel tiles: 10 halo rows for 8 output rows instead of 6 for 4 (the BatchNorm
 // transform of the halo was 22 % of that kernel, in-kernel stamps), half as many barrier pairs and tile set-ups; its 11 + 4 slots
 // replace the two 7 + 2 slot sets of the two-tiles-ahead prefetch (one 8-row MFMA phase covers a load round trip).
-__host__ __device__ constexpr bool wgrad_tall(bool nsplit, int tpg, int ma) { return nsplit && tpg == 9 && ma == 2; }
+#ifndef UBR_WGRAD_TALL
+#define UBR_WGRAD_TALL 1
+#endif
+__host__ __device__ constexpr bool wgrad_tall(bool nsplit, int tpg, int ma) { return UBR_WGRAD_TALL && nsplit && tpg == 9 && ma == 2; }
 __host__ __device__ constexpr int wgrad_xslots(bool nsplit, int tpg, int nb, int cpu, bool bigx, int ma = 0) {
   return (bigx ? 12 : (wgrad_tall(nsplit, tpg, ma) ? 11 : (nsplit ? 7 : (tpg == 25 ? 5 : (nb == 1 ? 3 : 6))))) * (8 / cpu);
 }

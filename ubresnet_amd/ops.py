@@ -101,6 +101,13 @@ def _timed(name):
     return deco
 
 
+def last_conv_kernel() -> str:
+    """kernel symbol (as rocprofv3 prints it) of this thread's last ubr_conv launch"""
+    buf = C.create_string_buffer(160)
+    L.lib().ubr_conv_last_kernel(buf, 160)
+    return buf.value.decode()
+
+
 def _tv(t: Optional[torch.Tensor]) -> L.Tensor:
     if t is None:
         return L.Tensor(None, 0, 0, 0)
