@@ -182,14 +182,33 @@ def test_aspp_resnet1_alias_both_import_styles():
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr
 
 
-def test_data_parallel_wrappers_raise_instead_of_training_on_nothing():
-    """nn.DataParallel replicas hold non-leaf broadcast copies of the parameters and DDP relies on AccumulateGrad hooks;
-    the fused autograd node would feed neither, so both must raise (SURVEY.md section 8b: errors must raise;
-    reference wrap: training/train_ubresnet2018_wlarcv2.py:99,103)."""
+def test_data_parallel_wrappers_get_gradients_through_autograd(monkeypatch):
+    """The reference wraps the model in nn.DataParallel (training/train_ubresnet2018_wlarcv2.py:99,103).  Its replicas hold
+    non-leaf broadcast copies of the parameters and DDP relies on AccumulateGrad hooks: under either wrapper the fused autograd
+    node must hand its gradients BACK THROUGH autograd (compatibility path) instead of installing .grad views that the
+    wrappers never see.  The executor is replaced by a stand-in here (no GPU): what is tested is the gradient routing."""
+    from ubresnet_amd import engine as E
     from ubresnet_amd.models.ub_uresnet import UResNet
     m = UResNet(num_classes=3, input_channels=1, inplanes=16)
     x = torch.zeros(1, 1, 32, 32)
-    # what torch.nn.parallel.replicate does to a replica: parameters become plain non-leaf tensors
+    calls = []
+
+    def fake_forward(self, xx, training, dt, save):
+        return torch.zeros(xx.shape[0], 3, xx.shape[2], xx.shape[3]), object()
+
+    def fake_backward(self, sv, g_out, grad_ready=None, allow_plan=True):
+        calls.append((grad_ready, allow_plan))
+        flat = torch.empty(self.grad_numel)
+        views = {}
+        for i, (name, p) in enumerate(self.grad_order):
+            o = self.grad_offsets[name]
+            views[id(p)] = flat[o:o + p.numel()].view(p.shape)
+            views[id(p)].fill_(float(i + 1))
+        return flat, views
+
+    monkeypatch.setattr(E.Engine, "forward", fake_forward)
+    monkeypatch.setattr(E.Engine, "backward", fake_backward)
+    # (a) what torch.nn.parallel.replicate does to a replica: parameters become plain non-leaf tensors
     reps = {id(mod): mod._replicate_for_data_parallel() for mod in m.modules()}
     for mod in m.modules():
         r = reps[id(mod)]
@@ -198,22 +217,43 @@ def test_data_parallel_wrappers_raise_instead_of_training_on_nothing():
                 r._modules[name] = reps[id(child)]
         for name, p in mod._parameters.items():
             if p is not None:
-                r._parameters[name] = p * 1.0            # non-leaf, requires_grad (stands in for Broadcast.apply output)
+                r._parameters[name] = p * 2.0            # non-leaf, requires_grad (stands in for Broadcast.apply output)
     replica = reps[id(m)]
     assert not replica.conv11.weight.is_leaf
-    with pytest.raises(RuntimeError, match="GradAllReducer"):
-        replica(x)
-    # DistributedDataParallel marks its forward through a class attribute
+    with pytest.warns(UserWarning, match="GradAllReducer"):
+        out = replica(x)
+    out.sum().backward()
+    assert calls[-1] == (None, False)                    # no early exchange, no launch plan on this path
+    order = {n: i + 1 for i, (n, _) in enumerate(m._grad_completion_order())}
+    for n, p in m.named_parameters():                    # the MASTER parameters received the gradients, through the * 2.0
+        assert p.grad is not None and torch.equal(p.grad, torch.full_like(p, 2.0 * order[n])), n
+    assert "_ubr_flat_grad" not in m.__dict__ and "_ubr_flat_grad" not in replica.__dict__
+    # (b) DistributedDataParallel marks its forward through a class attribute; its hooks hang on AccumulateGrad
+    m.zero_grad(set_to_none=True)
     from torch.nn.parallel import DistributedDataParallel as DDP
+    seen = []
+    hooks = [p.register_post_accumulate_grad_hook(lambda t: seen.append(1)) for p in m.parameters()]
     old = DDP._active_ddp_module
     DDP._active_ddp_module = object()
     try:
-        with pytest.raises(RuntimeError, match="DistributedDataParallel"):
-            m(x)
+        out = m(x)
     finally:
         DDP._active_ddp_module = old
+    out.sum().backward()
+    for h in hooks:
+        h.remove()
+    assert len(seen) == len(list(m.parameters())), "AccumulateGrad hooks (DDP's reducer) must fire for every parameter"
+    for n, p in m.named_parameters():
+        assert torch.equal(p.grad, torch.full_like(p, float(order[n]))), n
+    # (c) unwrapped: the fast path installs views of the flat buffer and offers the launch plan
+    m.zero_grad(set_to_none=True)
+    m(x).sum().backward()
+    assert calls[-1][1] is True and "_ubr_flat_grad" in m.__dict__
+    flat = m.__dict__["_ubr_flat_grad"]
+    assert all(p.grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr() for p in m.parameters())
     with pytest.raises(RuntimeError, match="input requires grad"):
         m(x.clone().requires_grad_(True))
+    monkeypatch.undo()
     # forward-only use is unaffected by the checks (it still refuses CPU tensors)
     with torch.no_grad(), pytest.raises(RuntimeError, match="ROCm device"):
         m(x)

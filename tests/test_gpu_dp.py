@@ -34,6 +34,8 @@ def _worker(rank, world, port, q, backend="gloo", mode="step"):
         dist.init_process_group("gloo", rank=rank, world_size=world)
     if mode == "accum":
         return _worker_accum(rank, world, q)
+    if mode == "steps":
+        return _worker_steps(rank, world, q)
     from oracle import uresnet_oracle as O
     from ubresnet_amd import synthetic
     from ubresnet_amd.dist import GradAllReducer, shard_range
@@ -136,6 +138,95 @@ def _worker_accum(rank, world, q):
     digest = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).double().sum().item()
     q.put((rank, bool(worst <= 1e-5), worst, digest))
     dist.destroy_process_group()
+
+
+def _worker_steps(rank, world, q):
+    """several optimizer steps under the reducer: from the second step on the backward pass is a replayed launch tape and the
+    gradient ranges are handed to the reducer through tape marks (ordered=False, dist.py) -- bitwise the same parameters as the
+    Python-scheduled run (ubresnet_amd.plan.ENABLED = False), and the same on every rank"""
+    from oracle import uresnet_oracle as O
+    from ubresnet_amd import plan, synthetic
+    from ubresnet_amd.dist import GradAllReducer, shard_range
+    from ubresnet_amd.models.ub_uresnet import UResNet
+    from ubresnet_amd.optim import FlatAdam
+    from ubresnet_amd.training.pixelwise_nllloss import PixelWiseNLLLoss
+    sd = O.seeded_state_dict(O.uresnet_schema(3, 1, 16, 16), 42)
+    crit = PixelWiseNLLLoss()
+    lo, hi = shard_range(4, rank, world)
+    res = {}
+    for enabled in (True, False):
+        plan.ENABLED = enabled
+        m = UResNet(3, 1, 16)
+        m.load_state_dict(sd)
+        m = m.cuda().train()
+        m.compute_dtype = torch.bfloat16
+        opt = FlatAdam(m, lr=1e-3, weight_decay=1e-4)
+        red = GradAllReducer(m, bucket_bytes=1 << 20)          # small buckets: several exchanges per backward
+        for i in range(4):
+            x, lab, wgt = synthetic.make_batch(4, 64, 64, 1000 + 10 * i)
+            loss = crit(m(torch.from_numpy(x[lo:hi]).cuda()), torch.from_numpy(lab[lo:hi]).cuda(), torch.from_numpy(wgt[lo:hi]).cuda())
+            opt.zero_grad()
+            loss.backward()
+            red.finish()
+            opt.step()
+        torch.cuda.synchronize()
+        eng = m.__dict__["_ubr_engine"]
+        replayed = any(p.bwd is not None and p.uses >= 3 for p in eng._planned.values())
+        res[enabled] = (opt.flat.clone(), replayed)
+    same = torch.equal(res[True][0], res[False][0])
+    digest = res[True][0].double().sum().item()
+    q.put((rank, bool(same and res[True][1] and not res[False][1] and torch.isfinite(res[True][0]).all().item()), 0.0, digest))
+    dist.destroy_process_group()
+
+
+def _ddp_worker(rank, world, port, q):
+    """the reference's own kind of wrap (training/train_ubresnet2018_wlarcv2.py:99,103: nn.DataParallel; here its
+    one-process-per-GPU sibling DistributedDataParallel, which works on a one-GPU box): gradients reach DDP's reducer through
+    the autograd compatibility path and the step equals the unwrapped one"""
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import warnings
+    from oracle import uresnet_oracle as O
+    from ubresnet_amd import synthetic
+    from ubresnet_amd.models.ub_uresnet import UResNet
+    from ubresnet_amd.training.pixelwise_nllloss import PixelWiseNLLLoss
+    sd = O.seeded_state_dict(O.uresnet_schema(3, 1, 16, 16), 42)
+    x, lab, wgt = [torch.from_numpy(a).cuda() for a in synthetic.make_batch(2, 64, 64, 1000)]
+    crit = PixelWiseNLLLoss()
+    plain = UResNet(3, 1, 16); plain.load_state_dict(sd); plain = plain.cuda().train()
+    crit(plain(x), lab, wgt).backward()
+    wrapped = UResNet(3, 1, 16); wrapped.load_state_dict(sd); wrapped = wrapped.cuda().train()
+    ddp = torch.nn.parallel.DistributedDataParallel(wrapped, device_ids=[0])
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        crit(ddp(x), lab, wgt).backward()
+    torch.cuda.synchronize()
+    warned = any("GradAllReducer" in str(i.message) for i in w)
+    ok = warned and all(p.grad is not None and torch.equal(p.grad, q_.grad) for p, q_ in zip(wrapped.parameters(), plain.parameters()))
+    opt = torch.optim.SGD(ddp.parameters(), lr=0.1)
+    before = wrapped.conv11.weight.detach().clone()
+    opt.step()
+    ok = ok and not torch.equal(before, wrapped.conv11.weight.detach())
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_distributed_data_parallel_wrapper_trains():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_ddp_worker, args=(0, 1, _free_port(), q))
+    p.start()
+    res = q.get(timeout=600)
+    p.join(timeout=60)
+    assert res == (0, True)
+
+
+def test_two_rank_replayed_steps_equal_python_scheduled_steps():
+    res = _run_two_ranks(mode="steps")
+    assert [r[:2] for r in res] == [(0, True), (1, True)]
+    assert res[0][3] == res[1][3], "replicas diverged: %r vs %r" % (res[0][3], res[1][3])
 
 
 def _run_two_ranks(backend="gloo", mode="step"):

@@ -600,7 +600,7 @@ def test_out_of_range_labels_raise():
     """F.nll_loss device-asserts on a target outside [0,C) other than ignore_index (training/pixelwise_nllloss.py:51); the
     HIP loss counts them and raises RuntimeError -- at the next loss call by default (asynchronous, no sync in the step)"""
     from ubresnet_amd.training import pixelwise_nllloss as PL
-    lp = torch.log_softmax(torch.randn(2, 3, 8, 8, device="cuda"), 1)
+    lp = torch.log_softmax(torch.randn(2, 3, 8, 8, device="cuda", requires_grad=True), 1)      # a loss that will be back-propagated
     tg = torch.randint(0, 3, (2, 8, 8), device="cuda")
     pw = torch.ones(2, 8, 8, device="cuda")
     crit = PL.PixelWiseNLLLoss()
@@ -624,6 +624,15 @@ def test_out_of_range_labels_raise():
         PL._label_check.mode = old
         PL._label_check.pending.clear()
     assert abs(float(crit(lp, tg, pw)) - float(good)) < 1e-7
+    # a bad label in the LAST batch has no "next call": flush() (end of epoch / before a checkpoint) reports it
+    crit(lp, bad, pw).backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="outside"):
+        crit.flush()
+    crit.flush()                                           # nothing pending: silent
+    # a loss nobody back-propagates (validation) reports immediately, as F.nll_loss would
+    with torch.no_grad(), pytest.raises(RuntimeError, match="outside"):
+        crit(lp.detach(), bad, pw)
+    PL._label_check.pending.clear()
 
 
 @pytest.mark.parametrize("dt", DTS + [torch.float16])

@@ -125,6 +125,62 @@ def test_plan_steps_aside_when_replay_is_not_safe(monkeypatch):
     assert next(iter(eng._planned.values())) is not before
 
 
+def test_dropped_pass_and_changed_batchnorm_scalars(monkeypatch):
+    """(a) a forward with gradients enabled whose loss is never back-propagated (the reference's validate() does exactly that,
+    training/train_ubresnet2018_wlarcv2.py:428) must not park the plan "in flight" for ever: the next train step replays;
+    (b) BatchNorm momentum / eps are baked into a tape at record time, so changing them retires the plan (the eager path
+    honours them at once); momentum=None is cumulative averaging as in nn.BatchNorm2d."""
+    monkeypatch.setattr(plan, "ENABLED", True)
+    m, _ = _make("uresnet", torch.float32)
+    crit = PixelWiseNLLLoss()
+    x, lab, wgt = [torch.from_numpy(a).cuda() for a in synthetic.make_batch(1, 64, 64, 1000)]
+    crit(m(x), lab, wgt).backward(); m.zero_grad()          # records forward and backward
+    crit(m(x), lab, wgt).backward(); m.zero_grad()          # replays
+    eng = m.__dict__["_ubr_engine"]
+    pl = next(iter(eng._planned.values()))
+    uses = pl.uses
+    out = m(x)                                               # gradients enabled, node dropped without a backward
+    assert pl.in_flight
+    del out
+    out2 = m(x)                                              # the plan is reclaimed, not bypassed
+    assert pl.uses == uses + 2 and pl.in_flight
+    crit(out2, lab, wgt).backward()
+    assert not pl.in_flight
+    g_ref = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone()
+    m.zero_grad()
+    # (b) momentum 0: running statistics must stop moving although the recorded tape used 0.1
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.momentum = 0.0
+    rm = m.bn10.running_mean.clone()
+    crit(m(x), lab, wgt).backward()
+    torch.cuda.synchronize()
+    assert torch.equal(m.bn10.running_mean, rm), "a replayed tape ignored the new BatchNorm momentum"
+    assert next(iter(eng._planned.values())) is not pl
+    assert torch.equal(torch.cat([p.grad.reshape(-1) for p in m.parameters()]), g_ref)
+    m.zero_grad()
+    # momentum=None: cumulative average over the batches seen since the reset
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.reset_running_stats()
+            mod.momentum = None
+    xs = [torch.from_numpy(synthetic.make_batch(1, 64, 64, 3000 + 7 * i)[0]).cuda() for i in range(3)]
+    means = []
+    for xi in xs:
+        with torch.no_grad():
+            m(xi)
+        means.append(m.bn1.running_mean.clone())
+    assert int(m.bn1.num_batches_tracked) == 3
+    ref = torch.nn.BatchNorm2d(16, momentum=None).cuda().train()
+    conv1 = torch.nn.Conv2d(1, 16, 7, 1, 3).cuda()
+    conv1.load_state_dict({"weight": m.conv1.weight.detach(), "bias": m.conv1.bias.detach()})
+    with torch.no_grad():
+        for xi, got in zip(xs, means):
+            ref(conv1(xi))
+            assert torch.allclose(got, ref.running_mean, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(m.bn1.running_var, ref.running_var, rtol=1e-3, atol=1e-5)
+
+
 def test_timed_replay_times_every_operator_and_changes_nothing(monkeypatch):
     """bench.py's breakdown: with plan.TIMED set, a replay brackets every taped launch with timing events on its own stream
     (ubr_tape_replay_timed) and reports one record per labelled operator call; the results of the step are those of an

@@ -445,21 +445,49 @@ def test_weights_updated_by_fused_optimizer_are_used():
     assert (after - want).abs().max().item() == 0.0
 
 
-def test_inplanes32_variant():
-    """UResNet(inplanes=32) -- the value training/train_ubresnet2018_wlarcv2.py:88 passes -- against the oracle."""
-    sd = O.seeded_state_dict(O.uresnet_schema(3, 1, 32, 16), 11)
-    x, lab, wgt = synthetic.make_batch(1, 64, 64, 1500)
-    xt = torch.from_numpy(x)
+def test_inplanes32_variant(golden_dir):
+    """UResNet(inplanes=32) -- the value training/train_ubresnet2018_wlarcv2.py:88 passes -- against the reference fixture
+    (tests/golden/uresnet_ip32_1x1x64x64.npz: the reference's own eval output, train output, loss and gradient norms) and,
+    tensor by tensor, against the fp64 oracle through the gradient rule of this file."""
+    g = np.load(os.path.join(golden_dir, "uresnet_ip32_1x1x64x64.npz"))
+    B, C, H, W, seed0, wseed = [int(v) for v in g["meta"]]
+    sd = O.seeded_state_dict(O.uresnet_schema(3, C, 32, 16), wseed)
+    x, lab, wgt = synthetic.make_batch(B, H, W, seed0)
+    xt, lt, wt = torch.from_numpy(x), torch.from_numpy(lab), torch.from_numpy(wgt)
     m = UResNet(num_classes=3, input_channels=1, inplanes=32)
     m.load_state_dict(sd)
-    m = m.cuda().train()
+    m = m.cuda().eval()
+    with torch.no_grad():
+        ev = m(xt.cuda()).cpu()
+    assert _rel(ev, torch.from_numpy(g["logp_eval"])) <= 1e-3
+    m.train()
     out = m(xt.cuda())
-    loss = PixelWiseNLLLoss()(out, torch.from_numpy(lab).cuda(), torch.from_numpy(wgt).cuda())
+    loss = PixelWiseNLLLoss()(out, lt.cuda(), wt.cuda())
     loss.backward()
-    ref = O.uresnet_forward(sd, xt, True, None)
-    assert _rel(out.detach().cpu(), ref) <= 1e-3
-    assert all(torch.isfinite(p.grad).all() for p in m.parameters())
+    ref = torch.from_numpy(g["logp_train"])
+    worst = ((out.detach().cpu() - ref).abs() - 1e-3 * ref.abs()).max().item()
+    assert worst <= 1e-4, "ip32 train log-probabilities: worst |a-b| - 1e-3|b| = %.3e" % worst
+    assert abs(loss.item() - float(g["loss"])) <= 1e-4 * abs(float(g["loss"]))
     assert sum(p.numel() for p in m.parameters()) == 72340003          # SURVEY.md section 8a row a5
+    _, g32, _, _ = O.train_step_grads(O.uresnet_forward, sd, xt, lt, wt)
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    _, g64, _, _ = O.train_step_grads(O.uresnet_forward, sd64, xt.double(), lt, wt.double())
+    params = dict(m.named_parameters())
+    rows, fails = [], []
+    for n in g64:
+        gv = params[n].grad.detach().cpu().double()
+        if n in ("conv1.bias", "conv10.bias"):
+            assert gv.abs().max().item() <= 1e-4, n
+            continue
+        rows.append(_grad_row(n, gv, g32[n].double(), g64[n]))
+        fails += _grad_verdict(rows[-1])
+    print("ip32 worst grad (max-abs rel, l2 rel, min cos):", max(r[1] for r in rows), max(r[3] for r in rows), min(r[5] for r in rows))
+    assert not fails, "; ".join(fails[:8])
+    for n, ref_norm in zip([str(v) for v in g["grad_names"]], g["grad_norms"]):
+        if n in ("conv1.bias", "conv10.bias"):
+            continue
+        norm = float(params[n].grad.double().norm())
+        assert abs(norm - ref_norm) <= 5e-2 * ref_norm + 1e-6, "grad norm %s: %g vs reference %g" % (n, norm, ref_norm)
 
 
 def test_device_stager_feeds_training():

@@ -169,3 +169,51 @@ def test_uresnet_nc4_normalised_eval(golden_dir, tag):
         assert np.array_equal(am.reshape(-1)[safe], g["argmax"].reshape(-1)[safe])
         if int(g["margin_hist"][:2].sum()) == 0:       # no pixel with a top-2 margin below 1e-3: the class map is pinned bit for bit
             assert hashlib.sha256(am.tobytes()).hexdigest() == str(g["argmax_sha256"])
+
+
+def test_aspp_normalised_eval_and_ip32(golden_dir):
+    """round-3 fixtures: the reference ASPP_ResNet in eval mode on reference-calibrated running statistics, and one train
+    step of the inplanes=32 U-ResNet that training/train_ubresnet2018_wlarcv2.py:88 builds"""
+    g = _load(golden_dir, "aspp_ip16_norm_1x3x64x96.npz")
+    B, C, H, W, seed0, wseed = [int(v) for v in g["meta"]]
+    sd = O.state_dict_with_bn_stats(O.seeded_state_dict(O.aspp_resnet_schema(3, C, 16), wseed), g["bn_keys"], g["bn_stats"])
+    x = synthetic.make_batch(B, H, W, seed0, planes=C)[0]
+    with torch.no_grad():
+        ev = O.aspp_resnet_forward(sd, torch.from_numpy(x), train=False)
+    assert np.abs(ev.numpy() - g["logp_eval"]).max() <= 2e-5          # log-probabilities are O(10) here
+    g = _load(golden_dir, "uresnet_ip32_1x1x64x64.npz")
+    B, C, H, W, seed0, wseed = [int(v) for v in g["meta"]]
+    sd = O.seeded_state_dict(O.uresnet_schema(3, C, 32, 16), wseed)
+    x, lab, wgt = synthetic.make_batch(B, H, W, seed0)
+    xt, lt, wt = torch.from_numpy(x), torch.from_numpy(lab), torch.from_numpy(wgt)
+    with torch.no_grad():
+        ev = O.uresnet_forward(sd, xt, train=False)
+    assert np.abs(ev.numpy() - g["logp_eval"]).max() <= 1e-6 * max(1.0, np.abs(g["logp_eval"]).max())
+    loss, grads, logp, _ = O.train_step_grads(O.uresnet_forward, sd, xt, lt, wt)
+    assert np.abs(logp.numpy() - g["logp_train"]).max() <= 2e-6 * max(1.0, np.abs(g["logp_train"]).max())
+    assert abs(float(loss) - float(g["loss"])) <= 1e-6 * abs(float(g["loss"]))
+    for n, ref_norm in zip([str(n) for n in g["grad_names"]], g["grad_norms"]):
+        gv = grads[n].reshape(-1).numpy().astype(np.float64)
+        assert abs(np.sqrt((gv ** 2).sum()) - ref_norm) <= 2e-5 * ref_norm + 1e-7, n
+
+
+def test_aspp_full_size_summary(golden_dir):
+    """BASELINE configs[3] at its real size (1 x 3 x 512 x 832): the oracle against what the reference's own ASPP_ResNet produced"""
+    g = _load(golden_dir, "aspp_ip16_1x3x512x832_summary.npz")
+    B, C, H, W, seed0, wseed = [int(v) for v in g["meta"]]
+    sd = O.seeded_state_dict(O.aspp_resnet_schema(3, C, 16), wseed)
+    x, lab, wgt = synthetic.make_batch(B, H, W, seed0, planes=C)
+    xt, lt, wt = torch.from_numpy(x), torch.from_numpy(lab), torch.from_numpy(wgt)
+    idx = g["sample_idx"]
+    with torch.no_grad():
+        ev = O.aspp_resnet_forward(sd, xt, train=False).numpy()
+    ref = g["sample_logp_eval"]
+    assert np.abs(ev.reshape(-1)[idx] - ref).max() <= 1e-5 * float(g["absmax_eval"])
+    am = ev.argmax(1).astype(np.uint8)
+    assert np.abs(np.bincount(am.reshape(-1), minlength=3) - g["class_counts_eval"]).sum() <= 2 * len(g["low_margin_idx_eval"]) + 2
+    loss, grads, logp, _ = O.train_step_grads(O.aspp_resnet_forward, sd, xt, lt, wt)
+    assert np.abs(logp.numpy().reshape(-1)[idx] - g["sample_logp_train"]).max() <= 2e-5 * max(1.0, float(g["absmax_train"]))
+    assert abs(float(loss) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    for n, ref_norm in zip([str(n) for n in g["grad_names"]], g["grad_norms"]):
+        gv = grads[n].reshape(-1).numpy().astype(np.float64)
+        assert abs(np.sqrt((gv ** 2).sum()) - ref_norm) <= 1e-3 * ref_norm + 1e-7, n

@@ -24,19 +24,37 @@ def compute_dtype(model) -> torch.dtype:
     return torch.float32
 
 
+class _PassToken:
+    """lives exactly as long as the autograd node of one forward pass (launch plans learn from it that a pass was dropped)"""
+    __slots__ = ("__weakref__",)
+
+
 class _NetFn(torch.autograd.Function):
     """One autograd node for the whole network: forward and backward are explicit kernel schedules."""
 
     @staticmethod
-    def forward(ctx, x, model, eng, dt, *params):
+    def forward(ctx, x, model, eng, dt, compat, *params):
         out, sv = eng.forward(x, model.training, dt, True)
-        ctx.eng, ctx.sv, ctx.params, ctx.model = eng, sv, params, model
+        ctx.eng, ctx.sv, ctx.params, ctx.model, ctx.compat = eng, sv, params, model, compat
+        plan = getattr(sv, "plan", None)
+        if plan is not None:
+            import weakref
+            ctx.tok = _PassToken()
+            plan.live = weakref.ref(ctx.tok)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
         if ctx.sv is None:
             raise RuntimeError("ubresnet_amd: backward called twice on the same forward pass (saved activations were released)")
+        if ctx.compat:
+            # nn.DataParallel replica (parameters are non-leaf broadcast copies) or a DistributedDataParallel wrapper: the
+            # gradients go back THROUGH autograd, so Broadcast's backward reduces them onto the master parameters and DDP's
+            # AccumulateGrad hooks see them.  Slow path (autograd handles 165 tensors one by one, the pass is scheduled from
+            # Python into a fresh flat buffer so nothing a later pass overwrites is handed out); GradAllReducer is the fast one.
+            flat, views = ctx.eng.backward(ctx.sv, g_out, None, allow_plan=False)
+            ctx.sv = None
+            return (None, None, None, None, None) + tuple(views[id(p)] if p.requires_grad else None for p in ctx.params)
         hook = getattr(ctx.model, "_grad_ready_hook", None)
         accumulating = any(p.requires_grad and p.grad is not None for p in ctx.params)
         if hook is not None and accumulating:
@@ -64,27 +82,33 @@ class _NetFn(torch.autograd.Function):
                 p.grad = g
             else:
                 p.grad.add_(g)
-        return (None, None, None, None) + (None,) * len(ctx.params)
+        return (None, None, None, None, None) + (None,) * len(ctx.params)
 
 
-_DP_MSG = ("ubresnet_amd: %s is not supported -- the network is one fused autograd node that installs parameter gradients as "
-           "views of a flat buffer, so %s would silently receive no gradients.  Data-parallel training runs one process per "
-           "GPU (torch.distributed, backend 'nccl' = RCCL) with ubresnet_amd.dist.GradAllReducer(model): see INTEGRATION.md "
-           "(replaces nn.DataParallel of training/train_ubresnet2018_wlarcv2.py:99,103).")
+_warned = set()
 
 
-def _check_wrappers(params, x):
-    """errors must raise: the wrappers below would train on no gradients without any message"""
-    for p in params:
-        if p.requires_grad and not p.is_leaf:
-            raise RuntimeError(_DP_MSG % ("nn.DataParallel replication (parameters are non-leaf broadcast copies)",
-                                          "the master parameters"))
-    ddp = getattr(torch.nn.parallel.DistributedDataParallel, "_active_ddp_module", None)
-    if ddp is not None:
-        raise RuntimeError(_DP_MSG % ("a DistributedDataParallel wrapper", "DDP's gradient hooks"))
+def _wrapper_mode(params, x, model):
+    """True when the reference's own wrap is in use (training/train_ubresnet2018_wlarcv2.py:99,103: nn.DataParallel; or a
+    DistributedDataParallel wrapper): parameter gradients must then travel through autograd instead of being installed as
+    views of the flat buffer -- the wrappers' reduction hooks would otherwise see nothing and the master parameters would
+    silently train on no gradients.  The path works, at the cost the fused node exists to avoid; a one-time warning names the
+    fast path (one process per GPU with ubresnet_amd.dist.GradAllReducer)."""
     if x.requires_grad:
         raise RuntimeError("ubresnet_amd: the input requires grad, but the HIP path computes no input gradient (no caller "
                            "of the reference needs one); detach the input")
+    kind = None
+    if any(p.requires_grad and not p.is_leaf for p in params):
+        kind = "nn.DataParallel replica"
+    elif getattr(torch.nn.parallel.DistributedDataParallel, "_active_ddp_module", None) is not None:
+        kind = "DistributedDataParallel"
+    if kind is not None and kind not in _warned:
+        _warned.add(kind)
+        import warnings
+        warnings.warn("ubresnet_amd: running under %s: gradients take the autograd compatibility path (one tensor at a time, no "
+                      "launch plans, no overlap of the exchange with backward).  The fast data-parallel path is one process "
+                      "per GPU with ubresnet_amd.dist.GradAllReducer(model) -- see INTEGRATION.md." % kind)
+    return kind is not None
 
 
 def run_network(model, kind: str, x: torch.Tensor) -> torch.Tensor:
@@ -93,7 +117,7 @@ def run_network(model, kind: str, x: torch.Tensor) -> torch.Tensor:
     params = tuple(p for _, p in eng.grad_order)
     need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
     if need_grad:
-        _check_wrappers(params, x)
-        return _NetFn.apply(x, model, eng, dt, *params)
+        compat = _wrapper_mode(params, x, model)
+        return _NetFn.apply(x, model, eng, dt, compat, *params)
     out, _ = eng.forward(x, model.training, dt, False)
     return out

@@ -1888,8 +1888,12 @@ extern "C" int ubr_conv(const ubr_conv_desc* d, void* stream) {
     for (int t = 0; t < d->ntaps && nat; ++t) nat = d->wt[t] == t;
     k.wlinear = nat ? 1 : 0;
   }
+#ifdef UBR_CONV_STAMPS      // diagnostic builds only (tools/build_variant.sh): phase masks give wrong results, the stamp pointer is a raw device address
   { static const int dbg = [] { const char* e = getenv("UBR_CONV_DBG"); return e ? atoi(e) : 0; }(); k.dbg = dbg; }
   { static const char* sp = getenv("UBR_CONV_STAMP_PTR"); k.stamps = sp ? (unsigned long long*)strtoull(sp, nullptr, 0) : nullptr; }
+#else
+  k.dbg = 0; k.stamps = nullptr;
+#endif
   k.wide_store = wide_ok ? 1 : 0;
   for (int t = 0; t < d->ntaps; ++t) { k.dy[t] = d->dy[t]; k.dx[t] = d->dx[t]; k.wt[t] = d->wt[t]; }
 

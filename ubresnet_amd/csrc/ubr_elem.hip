@@ -504,7 +504,12 @@ __global__ void bn_finalize_kernel(const double* stats, double count, const floa
                                    float* rmean, float* rvar, long long* nbt, float momentum, float eps, int C,
                                    float* scale, float* shift, float* mean, float* invstd) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0 && nbt != nullptr) *nbt += 1;
+  // momentum < 0 = nn.BatchNorm2d(momentum=None): cumulative moving average, factor 1 / (batches tracked, this one included).
+  // That form is launched as ONE workgroup, so every thread reads the counter before thread 0 advances it.
+  const long long n_old = nbt != nullptr ? *nbt : 0;
+  __syncthreads();
+  if (c == 0 && nbt != nullptr) *nbt = n_old + 1;
+  if (momentum < 0.f) momentum = (float)(1.0 / (double)(n_old + 1));
   if (c >= C) return;
   double s1 = 0.0, s2 = 0.0;
   // (all slot loads in flight at once: the compiler's partial unroll made this eight dependent round trips to L2, ~4 of the
@@ -1105,7 +1110,9 @@ extern "C" int ubr_bn_finalize(const double* stats, double count, const float* g
                                float* scale, float* shift, float* mean, float* invstd, void* stream) {
   UBR_CHECK(stats && gamma && beta && scale && shift && mean && invstd && C > 0 && count >= 1.0, "ubr_bn_finalize: bad arguments");
   UBR_CHECK((running_mean == nullptr) == (running_var == nullptr), "ubr_bn_finalize: running stats must come together");
-  ubr_launch(bn_finalize_kernel, dim3(ubr_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, stats, count, gamma, beta,
+  UBR_CHECK(momentum >= 0.f || (C <= 1024 && num_batches_tracked != nullptr), "ubr_bn_finalize: cumulative averaging (momentum < 0) needs C <= 1024 and the batch counter");
+  const dim3 grid(momentum < 0.f ? 1 : ubr_cdiv(C, 128)), block(momentum < 0.f ? ubr_cdiv(C, 64) * 64 : 128);
+  ubr_launch(bn_finalize_kernel, grid, block, 0, (hipStream_t)stream, stats, count, gamma, beta,
                      running_mean, running_var, (long long*)num_batches_tracked, momentum, eps, C, scale, shift, mean, invstd);
   UBR_LAUNCH_CHECK("ubr_bn_finalize");
   return UBR_OK;

@@ -609,8 +609,12 @@ extern "C" int ubr_wgrad(const ubr_wgrad_desc* d, void* stream) {
   UBR_CHECK((long)d->H * k.x_sy < (1L << 31) && (long)d->GH * k.g_sy < (1L << 31), "ubr_wgrad: image too large for 32-bit offsets");
   k.x_sy32 = (int)k.x_sy; k.x_sx32 = (int)k.x_sx; k.g_sy32 = (int)k.g_sy; k.g_sx32 = (int)k.g_sx;
   k.n_cot = d->Cout / (p.MA * 16);
+#ifdef UBR_WGRAD_STAMPS     // diagnostic builds only
   { static const int dbg = [] { const char* e = getenv("UBR_WGRAD_DBG"); return e ? atoi(e) : 0; }(); k.dbg = dbg; }
   { static const char* sp = getenv("UBR_WGRAD_STAMP_PTR"); k.stamps = sp ? (unsigned long long*)strtoull(sp, nullptr, 0) : nullptr; }
+#else
+  k.dbg = 0; k.stamps = nullptr;
+#endif
   for (int t = 0; t < d->ntaps; ++t) { k.dy[t] = d->dy[t]; k.dx[t] = d->dx[t]; }
   hipStream_t st = (hipStream_t)stream;
   switch (d->dtype) {

@@ -269,7 +269,7 @@ class Engine:
     def _finish_bn(self, site: BNSite, count: int, training: bool):
         m = site.mod
         if training:
-            mom = 0.1 if m.momentum is None else m.momentum
+            mom = -1.0 if m.momentum is None else m.momentum     # None: cumulative moving average (factor 1 / num_batches_tracked)
             track = m.track_running_stats and m.running_mean is not None
             ops.bn_finalize(site.stats, count, m.weight, m.bias, m.running_mean if track else None,
                             m.running_var if track else None, m.num_batches_tracked if track else None,
@@ -828,7 +828,7 @@ class Engine:
             return out, None
         sv.x, sv.x16, sv.c0, sv.amax = x, x16, c0, amax
         sv.enc, sv.aspp, sv.dec = (r1, r2, r3, r4, r5), (a3, a4, a5), (d1, d2, d3, d4, d5)
-        sv.d1o, sv.c10, sv.out, sv.dt = d1o, c10, out, dt
+        sv.d1o, sv.c10, sv.out, sv.dt = d1o, c10, out.detach(), dt     # (an alias without grad_fn: autograd attaches the node to `out` itself, and node -> ctx -> sv -> out would be a cycle)
         return out, sv
 
     def aspp_backward(self, sv, g_logp, grad_ready=None):
@@ -949,7 +949,7 @@ class Engine:
         sv.enc = (e1, e2, e3, e4, e5)
         sv.dec = (d1, d2, d3, d4, d5)
         sv.cats = (cat1, cat2, cat3, cat4, cat5)
-        sv.d1o, sv.c10, sv.out, sv.dt = d1o, c10, out, dt
+        sv.d1o, sv.c10, sv.out, sv.dt = d1o, c10, out.detach(), dt     # (an alias without grad_fn: autograd attaches the node to `out` itself, and node -> ctx -> sv -> out would be a cycle)
         return out, sv
 
     def uresnet_backward(self, sv: Saved, g_logp: torch.Tensor, grad_ready: Optional[Callable] = None):

@@ -143,6 +143,7 @@ class PlannedPass:
         self.sv = None
         self.flat = self.views = None
         self.in_flight = False
+        self.live = None         # weakref to the autograd node's token of the pass in flight (autograd_fn._NetFn)
         self.uses = 0
 
 
@@ -163,6 +164,9 @@ def _signature(model):
         for t in m._buffers.values():
             if t is not None:
                 sig.append(t.data_ptr())
+        if hasattr(m, "momentum") and hasattr(m, "eps"):
+            # host scalars a tape bakes in at record time (Engine._finish_bn): changing them must retire the plan too
+            sig.append((m.momentum, m.eps, getattr(m, "track_running_stats", None)))
     return tuple(sig)
 
 
@@ -192,6 +196,10 @@ def forward(eng, x, training, dt, save):
     if plan is not None and plan.sig != sig:
         del eng._planned[key]            # parameter or buffer storage was replaced: the baked addresses are stale
         plan = None
+    if plan is not None and plan.in_flight and plan.live is not None and plan.live() is None:
+        # the pass in flight was dropped without a backward (its autograd node is gone: e.g. a forward with gradients enabled
+        # whose loss was never back-propagated, as the reference's validate() does, train_ubresnet2018_wlarcv2.py:428)
+        plan.in_flight = False
     if plan is not None and plan.in_flight:
         return eng.forward_eager(x, training, dt, save)      # a second forward before the first one's backward
     streams = _streams(eng, dev)
@@ -223,10 +231,11 @@ def forward(eng, x, training, dt, save):
         eng._bwd_packed = None           # (an eager backward after a replayed forward repacks its own weight images)
         sv = plan.sv
         if sv is not None:
-            sv.x, sv.out = x, out
+            sv.x, sv.out = x, out.detach()
     plan.uses += 1
     if save:
         plan.in_flight = True
+        plan.live = None
         sv.plan = plan
     return out, sv
 

@@ -60,6 +60,14 @@ class _LabelCheck:
             ev.synchronize()
             self.poll()
 
+    def flush(self):
+        """wait for every outstanding count and report it now (end of an epoch, before a checkpoint, after validation)"""
+        if torch.cuda.is_current_stream_capturing():
+            return
+        for ev, _, _, _ in self.pending:
+            ev.synchronize()
+        self.poll()
+
     def poll(self):
         if self.pending and torch.cuda.is_current_stream_capturing():
             return
@@ -77,7 +85,7 @@ _label_check = _LabelCheck()
 
 class _PixelNLLFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, predict, target, pixelweights, classw, ignore_index):
+    def forward(ctx, predict, target, pixelweights, classw, ignore_index, report_now=False):
         L.require_cuda(predict, "predict")
         if predict.dtype != torch.float32 or pixelweights.dtype != torch.float32 or target.dtype != torch.int64:
             raise RuntimeError("PixelWiseNLLLoss: expected predict/pixelweights float32 and target int64, got %s/%s/%s"
@@ -92,6 +100,10 @@ class _PixelNLLFn(torch.autograd.Function):
         ops.zero_(acc)
         ops.pixelwise_nll_fwd(predict, target, pixelweights, classw, ignore_index, acc, bad=acc[L.STAT_SLOTS:])
         _label_check.watch(acc[L.STAT_SLOTS:], predict.shape[1], ignore_index)
+        if report_now:
+            # a loss nobody back-propagates (validation, a one-off evaluation): there may be no "next call" to report at, and the
+            # step-time argument for the asynchronous check does not apply -- report now, as F.nll_loss would
+            _label_check.flush()
         loss = torch.empty((), dtype=torch.float32, device=predict.device)
         ops.cast_f64_to_f32(acc, loss, 1, 1.0 / float(target.numel()), stride=1)
         ctx.save_for_backward(target, pixelweights)
@@ -104,7 +116,7 @@ class _PixelNLLFn(torch.autograd.Function):
         g = torch.empty(ctx.shape, dtype=torch.float32, device=target.device)
         g_loss = g_loss.contiguous().to(torch.float32)
         ops.pixelwise_nll_bwd(g_loss, target, pixelweights, ctx.classw, ctx.ignore_index, ctx.shape, g)
-        return g, None, None, None, None
+        return g, None, None, None, None, None
 
 
 class PixelWiseNLLLoss(nn.modules.loss._WeightedLoss):
@@ -114,6 +126,14 @@ class PixelWiseNLLLoss(nn.modules.loss._WeightedLoss):
         self.size_average = size_average
         self.ignore_index = ignore_index
         self.reduce = False
+
+    @staticmethod
+    def flush():
+        """Out-of-range target labels are counted on the device and reported one loss call later (no host/device sync in the
+        train step; a loss computed without gradients reports immediately).  Call this at the end of an epoch or before a
+        checkpoint to raise for the last batches too.  The reference's F.nll_loss asserts immediately
+        (training/pixelwise_nllloss.py:51)."""
+        _label_check.flush()
 
     def forward(self, predict, target, pixelweights):
         """
@@ -126,4 +146,5 @@ class PixelWiseNLLLoss(nn.modules.loss._WeightedLoss):
         classw = self.weight
         if classw is not None:
             classw = classw.to(device=predict.device, dtype=torch.float32).contiguous()
-        return _PixelNLLFn.apply(predict, target, pixelweights, classw, self.ignore_index)
+        report_now = not (torch.is_grad_enabled() and predict.requires_grad)      # (decided here: grad mode is off inside Function.forward)
+        return _PixelNLLFn.apply(predict, target, pixelweights, classw, self.ignore_index, report_now)
