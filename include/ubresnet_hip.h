@@ -101,6 +101,18 @@ typedef struct {
                               * bit 1 = ReLU after it:  out = relu?( relu?(conv + bias) + addend )  -- with both bits
                               * this is the whole BasicBlock tail (models/common_layers.py:47-56) */
   int32_t pad_;
+  /* Training, data-gradient convs (both optional; zero-initialise the descriptor):
+   * addend_mask -- the addend is gated by the ReLU bit mask of a block tail (ubr_block_tail_fwd_masked: one byte per output
+   *   pixel and 16-byte channel unit, [N*OH*OW][Cout / channels-per-unit], bit e = channel e of the unit):
+   *   out = conv + addend * bit.  This re-forms the skip gradient g_out*[out>0] of an identity block from g_out and the mask, so
+   *   the tail's backward need not write it (ubr_block_tail_bwd_apply_fin with g_sc == NULL).
+   * bnb_c -- BatchNorm-backward sums in the epilogue: `stats` then receives, per output channel, sum g_y and sum g_y*xhat of
+   *   a = max(bn(c), 0)  (g = this conv's output rounded to the storage type, exactly what a separate ubr_bn_bwd_reduce over
+   *   the stored tensor reads; g_y = g*[bn(c) > 0]; xhat = (c - mean)*invstd) instead of the output's own statistics: the
+   *   reduce pass of ubr_bn_bwd_* for one extra read of c.  c is a view of the OUTPUT grid.  Stripes: UBR_RED_SLOTS. */
+  const uint8_t* addend_mask;
+  ubr_tensor bnb_c;
+  const float *bnb_mean, *bnb_scale, *bnb_shift, *bnb_invstd;
 } ubr_conv_desc;
 
 int ubr_conv(const ubr_conv_desc* d, void* stream);

@@ -175,6 +175,46 @@ def test_conv_pc_equals_igemm_bitwise(dt, shape):
 
 
 @pytest.mark.parametrize("dt", DTS + [torch.float16])
+@pytest.mark.parametrize("shape", [(2, 32, 64, 16, 16, 3), (1, 16, 64, 32, 32, 3), (2, 16, 32, 64, 64, 3), (1, 8, 16, 128, 128, 3), (1, 32, 64, 16, 16, 7),
+                                   (1, 12, 20, 48, 32, 3)])
+def test_conv_training_epilogues(dt, shape):
+    """ubr_conv_desc.bnb_c: the conv's `stats` are the BatchNorm-backward sums of a = relu(bn(c)) for g = its (stored) output --
+    equal to a separate ubr_bn_bwd_reduce over the stored tensor; ubr_conv_desc.addend_mask: out = conv + addend * bit --
+    bitwise what the unmasked conv gives on a pre-masked addend.  Thin (<= 32 channels), row-stationary 7x7 and generic kernels."""
+    N, H, W, Cin, Cout, ksz = shape
+    x = nhwc(rnd(dt, gen(N, Cin, H, W, seed=21)), dt)
+    w = gen(Cout, Cin, ksz, ksz, seed=22, scale=(2.0 / (ksz * ksz * Cin)) ** 0.5)
+    wp = ops.pack_weights(w.to(DEV), dt, Cout, Cin, Cin * ksz * ksz, ksz * ksz, ksz * ksz)
+    taps = ops.conv_taps(ksz, 1, ksz // 2)
+    c = nhwc(rnd(dt, gen(N, Cout, H, W, seed=23)), dt)
+    mean, scale, shift, invstd = [(gen(Cout, seed=24 + i) * 0.3 + (0.0 if i in (0, 2) else 1.0)).to(DEV) for i in range(4)]
+    y0 = torch.empty((N, H, W, Cout), dtype=dt, device=DEV)
+    ops.conv(x, wp, y0, taps, Cout)
+    red0 = statbuf(2 * Cout)
+    ops.bn_bwd_reduce(y0, None, c, scale, shift, mean, invstd, True, red0)
+    y1 = torch.full_like(y0, float("nan"))
+    red1 = statbuf(2 * Cout)
+    ops.conv(x, wp, y1, taps, Cout, bnb=(c, mean, scale, shift, invstd), stats=red1)
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y0)
+    a, b = slotsum(red1, 2 * Cout), slotsum(red0, 2 * Cout)
+    assert torch.allclose(a, b, rtol=1e-5, atol=2e-6 * float(b.abs().max()) + 2e-5), "fused BatchNorm-backward sums: %.3e" % float((a - b).abs().max())
+    assert float(red1.view(SLOTS, -1)[8:].abs().max()) == 0.0          # UBR_RED_SLOTS stripes only
+    # masked addend
+    cpu_ = 4 if dt == torch.float32 else 8
+    if Cout % cpu_ == 0:
+        ad = nhwc(rnd(dt, gen(N, Cout, H, W, seed=29)), dt)
+        mask = torch.randint(0, 256, (N * H * W * (Cout // cpu_),), dtype=torch.uint8, device=DEV)
+        bits = ((mask.view(N, H, W, Cout // cpu_, 1) >> torch.arange(cpu_, device=DEV, dtype=torch.uint8)) & 1).reshape(N, H, W, Cout).bool()
+        ad_masked = torch.where(bits, ad, torch.zeros_like(ad))
+        y2, y3 = torch.empty_like(y0), torch.full_like(y0, float("nan"))
+        ops.conv(x, wp, y2, taps, Cout, addend=ad_masked)
+        ops.conv(x, wp, y3, taps, Cout, addend=ad, addend_mask=mask)
+        torch.cuda.synchronize()
+        assert torch.equal(y3, y2)
+
+
+@pytest.mark.parametrize("dt", DTS + [torch.float16])
 @pytest.mark.parametrize("chans", [(32, 16), (128, 64)])
 def test_deconv_forward_and_grads(dt, chans):
     """ConvTranspose2d(k4,s2,p1) as 4 phases into a concat slice; its data and weight gradients."""

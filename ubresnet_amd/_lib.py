@@ -63,6 +63,9 @@ class ConvDesc(C.Structure):
         ("tile_hint", C.c_int32),
         ("act", C.c_int32),
         ("pad_", C.c_int32),
+        ("addend_mask", C.c_void_p),
+        ("bnb_c", Tensor),
+        ("bnb_mean", C.c_void_p), ("bnb_scale", C.c_void_p), ("bnb_shift", C.c_void_p), ("bnb_invstd", C.c_void_p),
     ]
 
 

@@ -41,6 +41,11 @@ struct ConvK {
   int wl_off, halo_off, red_off, xfc_off;        // LDS carve offsets
   int epilogue, act, wide_store, dbg, wlinear, N;
   int buf_stride, ncot;                          // conv_pc_kernel: bytes between its two LDS buffers; cout tiles of the layer
+  // training epilogues of the data-gradient convs (ubr_conv_desc.addend_mask / bnb_c)
+  const uint8_t* ad_mask; int ad_mask_cu;        // ReLU bit mask gating the addend; units per pixel of the mask
+  const char* bc; long bc_sn, bc_sy, bc_sx;      // saved activation c of the BatchNorm-backward sums (view of the output grid)
+  const float *bmean, *bscale, *bshift, *binvstd;
+  int nslots;                                    // stripes of `stats` in use
   int8_t dy[UBR_MAX_TAPS], dx[UBR_MAX_TAPS];
   uint8_t wt[UBR_MAX_TAPS];
   unsigned long long* stamps;                    // diagnostic build (-DUBR_CONV_STAMPS): per-workgroup phase cycle sums
@@ -69,6 +74,39 @@ template <> __device__ __forceinline__ void load4<bf16_t>(const char* p, float* 
 template <> __device__ __forceinline__ void load4<f16_t>(const char* p, float* v) {
   f16x4_t h = __builtin_bit_cast(f16x4_t, *reinterpret_cast<const uint2*>(p));
   v[0] = (float)h[0]; v[1] = (float)h[1]; v[2] = (float)h[2]; v[3] = (float)h[3];
+}
+
+// v rounded to the storage type (what a later pass would read back from the stored tensor)
+template <typename T> __device__ __forceinline__ void round4(const float* v, float* r);
+template <> __device__ __forceinline__ void round4<float>(const float* v, float* r) { r[0] = v[0]; r[1] = v[1]; r[2] = v[2]; r[3] = v[3]; }
+template <> __device__ __forceinline__ void round4<bf16_t>(const float* v, float* r) {
+  // round-to-nearest-even on the bit pattern (integer ops; NaN kept as NaN), the result v_cvt_pk_bf16_f32 gives.  A compiler-placed
+  // v_cvt_pk_bf16_f32 next to the hand-scheduled convert + v_permlane16_swap block of the store path reproduced that block's
+  // known failure (lanes 12-15 of the even quads, second dword) in the variants that round here as well.
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t u = __float_as_uint(v[i]);
+    const uint32_t rne = (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
+    r[i] = __uint_as_float((u & 0x7fffffffu) > 0x7f800000u ? (u | 0x00400000u) & 0xffff0000u : rne);
+  }
+}
+template <> __device__ __forceinline__ void round4<f16_t>(const float* v, float* r) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = (float)(_Float16)v[i];
+}
+// BatchNorm-backward sums of one 4-channel group: g_y = g*[bn(c) > 0], xhat = (c - mean)*invstd (same operations as bn_bwd_kernel)
+__device__ __forceinline__ void bnb_accumulate(const float* g, const float* c, const float4& mu, const float4& sc, const float4& sh, const float4& is,
+                                               float* s1, float* s2) {
+  const float m[4] = {mu.x, mu.y, mu.z, mu.w}, a[4] = {sc.x, sc.y, sc.z, sc.w}, b[4] = {sh.x, sh.y, sh.z, sh.w}, iv[4] = {is.x, is.y, is.z, is.w};
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float d = c[r] - m[r];
+    const float bn = __builtin_fmaf(d, a[r], b[r]);
+    const float xh = d * iv[r];
+    const float gy = bn > 0.f ? g[r] : 0.f;
+    s1[r] += gy;
+    s2[r] += gy * xh;
+  }
 }
 
 // LDS bytes per halo pixel.  A ds_read_b128 is served in four groups of 16 lanes that each pair 8 lanes of one quad with the
@@ -425,13 +463,20 @@ __global__ __launch_bounds__(256, ((NT == 4 && FW <= 2 && !PIPE) ? 4 : 2)) void 
     for (int r = 0; r < 4; ++r) { s1[j][r] = 0.f; s2[j][r] = 0.f; }
 
 #pragma unroll
-  for (int i = 0; i < FW; ++i) {
-    const int f = wave * FW + i;
-    const int oy = oy0 + f / TWF, ox = ox0 + (f % TWF) * 16 + l16;
-    const bool valid = (oy < k.OH) && (ox < k.OW);
+  for (int j = 0; j < NT; ++j) {
+    const int ch = n0 + j * 16 + 4 * q;
+    // BatchNorm-backward sums: this group's per-channel constants (one set per cout fragment, outside the pixel loop)
+    float4 bmu = make_float4(0.f, 0.f, 0.f, 0.f), bsc = bmu, bsh = bmu, bis = bmu;
+    const bool bnb = k.bc != nullptr && ch < k.Cout;
+    if (bnb) {
+      bmu = *reinterpret_cast<const float4*>(k.bmean + ch); bsc = *reinterpret_cast<const float4*>(k.bscale + ch);
+      bsh = *reinterpret_cast<const float4*>(k.bshift + ch); bis = *reinterpret_cast<const float4*>(k.binvstd + ch);
+    }
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int ch = n0 + j * 16 + 4 * q;
+    for (int i = 0; i < FW; ++i) {
+      const int f = wave * FW + i;
+      const int oy = oy0 + f / TWF, ox = ox0 + (f % TWF) * 16 + l16;
+      const bool valid = (oy < k.OH) && (ox < k.OW);
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bs[j][r];
@@ -442,6 +487,11 @@ __global__ __launch_bounds__(256, ((NT == 4 && FW <= 2 && !PIPE) ? 4 : 2)) void 
       if (k.ad != nullptr && valid && ch < k.Cout) {
         float a4[4];
         load4<T>(k.ad + (long)n * k.a_sn + (long)oy * k.a_sy + (long)ox * k.a_sx + (long)ch * ESZ, a4);
+        if (k.ad_mask != nullptr) {
+          const unsigned mb = (unsigned)k.ad_mask[(((long)n * k.OH + oy) * k.OW + ox) * k.ad_mask_cu + ch / CPU] >> (ch % CPU);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) a4[r] = ((mb >> r) & 1u) ? a4[r] : 0.f;
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += a4[r];
       }
@@ -450,8 +500,17 @@ __global__ __launch_bounds__(256, ((NT == 4 && FW <= 2 && !PIPE) ? 4 : 2)) void 
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
       }
       if (k.stats != nullptr && valid) {
+        if (k.bc != nullptr) {
+          if (bnb) {
+            float g4[4], c4[4];
+            round4<T>(v, g4);
+            load4<T>(k.bc + (long)n * k.bc_sn + (long)oy * k.bc_sy + (long)ox * k.bc_sx + (long)ch * ESZ, c4);
+            bnb_accumulate(g4, c4, bmu, bsc, bsh, bis, s1[j], s2[j]);
+          }
+        } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { s1[j][r] += v[r]; s2[j][r] += v[r] * v[r]; }
+          for (int r = 0; r < 4; ++r) { s1[j][r] += v[r]; s2[j][r] += v[r] * v[r]; }
+        }
       }
       if (k.epilogue == 0) {
         if (valid && ch < k.Cout)
@@ -498,7 +557,7 @@ __global__ __launch_bounds__(256, ((NT == 4 && FW <= 2 && !PIPE) ? 4 : 2)) void 
         double a = 0.0, b = 0.0;
 #pragma unroll
         for (int w = 0; w < 4; ++w) { a += (double)red[(w * TN + tid) * 2]; b += (double)red[(w * TN + tid) * 2 + 1]; }
-        double* st = k.stats + (size_t)(blockIdx.x % UBR_STAT_SLOTS) * 2 * k.Cout;
+        double* st = k.stats + (size_t)(blockIdx.x % k.nslots) * 2 * k.Cout;
         atomicAdd(&st[ch], a);
         atomicAdd(&st[k.Cout + ch], b);
       }
@@ -588,6 +647,11 @@ struct ThinK {
   int8_t dy[UBR_MAX_TAPS], dx[UBR_MAX_TAPS];
   uint8_t wt[UBR_MAX_TAPS];
   unsigned long long* stamps;                    // diagnostic build (-DUBR_CONV_STAMPS)
+  // training epilogues of the data-gradient convs (EXT = 2: ReLU bit mask on the addend; EXT = 1: BatchNorm-backward sums)
+  const uint8_t* ad_mask; int ad_mask_cu; unsigned mask_bytes;
+  const char* bc; long bc_sn; int bc_sy, bc_sx; unsigned bc_bytes;
+  const float *bmean, *bscale, *bshift, *binvstd;
+  int nslots;
 };
 
 // exact unsigned division of small operands by a runtime divisor: magic = ceil(2^32 / d) for d >= 2 (valid while n * d < 2^32);
@@ -601,8 +665,9 @@ __device__ __forceinline__ unsigned udiv_magic(unsigned n, unsigned magic) { ret
 // cout tiles: in the generic tap loop every MFMA needs a fresh 1 KB fragment and the 7x7 layers were LDS-read bound,
 // 151 us alone, ~190 us beside the weight-gradient stream.)  The horizontal taps are padded from 7 to 8 so that a K-step's two
 // taps share a row (56 virtual taps, the host supplies their table; the pad tap has zero weights): +12 % MFMAs.
-template <typename T, int FW, int NT, int TWF, int UPB, bool XF, bool LSM, bool ROW7 = false>
-__global__ __launch_bounds__(256, (ROW7 ? 2 : 3)) void conv_thin_kernel(const ThinK k) {
+template <typename T, int FW, int NT, int TWF, int UPB, bool XF, bool LSM, bool ROW7 = false, int EXT = 0>
+__global__ __launch_bounds__(256, ((ROW7 || (EXT == 1 && NT == 2)) ? 2 : 3)) void conv_thin_kernel(const ThinK k) {
+  static_assert(EXT == 0 || (!XF && !LSM), "the training epilogues belong to the data-gradient convs (no transform on load, NHWC output)");
   constexpr int TN = NT * 16;
   constexpr int TH = 4 * FW / TWF;
   constexpr int TW = TWF * 16;
@@ -702,6 +767,14 @@ __global__ __launch_bounds__(256, (ROW7 ? 2 : 3)) void conv_thin_kernel(const Th
       xfc[i] = src[ch];
     }
   }
+  if constexpr (EXT == 1) {
+    // BatchNorm-backward sums: mean | scale | shift | invstd of this workgroup's TN output channels, [4][TN] floats
+    for (int i = tid; i < 4 * TN; i += 256) {
+      const int which = i / TN, ch = n0 + (i - which * TN);
+      const float* src = which == 0 ? k.bmean : (which == 1 ? k.bscale : (which == 2 ? k.bshift : k.binvstd));
+      xfc[i] = ch < k.Cout ? src[ch] : 0.f;
+    }
+  }
   int* wsrc = tbl + 4 * k.steps;
   for (int u = tid; u < 4 * k.steps; u += 256) {
     int off = 0, v = -1;
@@ -753,7 +826,7 @@ __global__ __launch_bounds__(256, (ROW7 ? 2 : 3)) void conv_thin_kernel(const Th
     }
   }
 
-  if constexpr (XF) __syncthreads();          // the BatchNorm constants in LDS are read before the tile loop's first barrier
+  if constexpr (XF || EXT == 1) __syncthreads();          // the BatchNorm constants in LDS are read before the tile loop's first barrier
   // fragment addressing: fragment f = wave*FW + g0 + i of the tile sits at row f/2, column half f%2
   const int fb0 = (((wave * FW) / TWF) * k.HW + l16) * PIXB;          // group 0, fragment 0 of this wave
   const int rowb = k.HW * PIXB;
@@ -767,6 +840,15 @@ __global__ __launch_bounds__(256, (ROW7 ? 2 : 3)) void conv_thin_kernel(const Th
   int vo_ad[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) vo_ad[j] = ((wave * FW) / TWF) * k.a_sy + l16 * k.a_sx + (n0 + j * 16 + 4 * q) * ESZ;
+  int vo_c[EXT == 1 ? NT : 1], vo_m[EXT == 2 ? NT : 1];
+  if constexpr (EXT == 1) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) vo_c[j] = ((wave * FW) / TWF) * k.bc_sy + l16 * k.bc_sx + (n0 + j * 16 + 4 * q) * ESZ;
+  }
+  if constexpr (EXT == 2) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) vo_m[j] = (((wave * FW) / TWF) * k.OW + l16) * k.ad_mask_cu + (n0 + j * 16 + 4 * q) / CPU;
+  }
   float s1[NT][4], s2[NT][4];
 #pragma unroll
   for (int j = 0; j < NT; ++j)
@@ -819,6 +901,16 @@ __global__ __launch_bounds__(256, (ROW7 ? 2 : 3)) void conv_thin_kernel(const Th
     __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)(k.y + (long)n * k.y_sn), 0, (int)k.y_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc((void*)(k.ad != nullptr ? k.ad + (long)n * k.a_sn : k.x), 0, k.ad != nullptr ? (int)k.a_bytes : 0, 0x00020000);
     const int ybase = oy0 * k.y_sy + ox0 * k.y_sx, abase = oy0 * k.a_sy + ox0 * k.a_sx;
+    __amdgpu_buffer_rsrc_t cr = yr, mr = yr;
+    int cbase = 0, mbase = 0;
+    if constexpr (EXT == 1) {
+      cr = __builtin_amdgcn_make_buffer_rsrc((void*)(k.bc + (long)n * k.bc_sn), 0, (int)k.bc_bytes, 0x00020000);
+      cbase = oy0 * k.bc_sy + ox0 * k.bc_sx;
+    }
+    if constexpr (EXT == 2) {
+      mr = __builtin_amdgcn_make_buffer_rsrc((void*)(k.ad_mask + (long)n * k.mask_bytes), 0, (int)k.mask_bytes, 0x00020000);
+      mbase = (oy0 * k.OW + ox0) * k.ad_mask_cu;
+    }
     UBR_TSTAMP(tL);
 
 #pragma unroll 1
@@ -834,6 +926,26 @@ __global__ __launch_bounds__(256, (ROW7 ? 2 : 3)) void conv_thin_kernel(const Th
             const int so = abase + ((g0 + i) / TWF) * k.a_sy;
             if constexpr (WIDE) adv2[i][j] = __builtin_amdgcn_raw_buffer_load_b64(ar, vo_ad[j] + (i % TWF) * 16 * k.a_sx, so, 0);
             else adv4[i][j] = __builtin_amdgcn_raw_buffer_load_b128(ar, vo_ad[j] + (i % TWF) * 16 * k.a_sx, so, 0);
+          }
+      }
+      unsigned admk[EXT == 2 ? FH : 1][EXT == 2 ? NT : 1];      // ReLU bit-mask byte of this lane's channel unit
+      ubr_u4 cv4[EXT == 1 ? FH : 1][EXT == 1 ? NT : 1];         // saved activation c of the BatchNorm-backward sums (fp32: 16 bytes)
+      ubr_u2 cv2[EXT == 1 ? FH : 1][EXT == 1 ? NT : 1];         // (16-bit types: 8 bytes)
+      if constexpr (EXT == 2) {
+#pragma unroll
+        for (int i = 0; i < FH; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            admk[i][j] = __builtin_amdgcn_raw_buffer_load_b8(mr, vo_m[j] + (i % TWF) * 16 * k.ad_mask_cu, mbase + ((g0 + i) / TWF) * k.OW * k.ad_mask_cu, 0);
+      }
+      if constexpr (EXT == 1) {
+#pragma unroll
+        for (int i = 0; i < FH; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const int so = cbase + ((g0 + i) / TWF) * k.bc_sy;
+            if constexpr (WIDE) cv2[i][j] = __builtin_amdgcn_raw_buffer_load_b64(cr, vo_c[j] + (i % TWF) * 16 * k.bc_sx, so, 0);
+            else cv4[i][j] = __builtin_amdgcn_raw_buffer_load_b128(cr, vo_c[j] + (i % TWF) * 16 * k.bc_sx, so, 0);
           }
       }
       f32x4 acc[FH][NT];
@@ -892,6 +1004,11 @@ __global__ __launch_bounds__(256, (ROW7 ? 2 : 3)) void conv_thin_kernel(const Th
           for (int j = 0; j < NT; ++j) acc[i][j] = mma_step<T>(acc[i][j], wf[j], a[i]);
       }
       }   // !ROW7
+      // The accumulators are read right below.  Variants of this kernel with more registers in flight (the training epilogues)
+      // stored stale values in lanes 12-15 of every 16-lane row -- the columns an MFMA's LAST pass writes -- for the accumulator
+      // of the last-issued MFMA: the matrix result had not landed when the first VALU read it.  Two s_nop 15 cover the longest
+      // MFMA here (8 passes); they cost ~30 cycles per 72..448 MFMAs.
+      asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
       UBR_TSTAMP(tC);
 
       // ---- epilogue of this fragment group ----
@@ -917,14 +1034,34 @@ __global__ __launch_bounds__(256, (ROW7 ? 2 : 3)) void conv_thin_kernel(const Th
                 const uint4 raw = __builtin_bit_cast(uint4, adv4[i + h][j]);
                 ET<T>::unpack(raw, a4);
               }
+              if constexpr (EXT == 2) {
+                // (a * bit + v as one fused multiply-add: exact for bit in {0, 1}, i.e. the same sum as the unmasked form)
+                const unsigned mb = (admk[i + h][j] & 0xffu) >> ((n0 + j * 16 + 4 * q) % CPU);
 #pragma unroll
-              for (int r = 0; r < 4; ++r) v[h][r] += a4[r];
+                for (int r = 0; r < 4; ++r) v[h][r] = __builtin_fmaf(a4[r], (float)((mb >> r) & 1u), v[h][r]);
+              } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[h][r] += a4[r];
+              }
             }
             if (k.act & 2) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[h][r] = fmaxf(v[h][r], 0.f);
             }
-            if (k.stats != nullptr) {
+            if constexpr (EXT == 1) {
+              float g4[4], c4[4];
+              round4<T>(v[h], g4);
+              if constexpr (WIDE) {
+                const uint2 raw = make_uint2(cv2[i + h][j][0], cv2[i + h][j][1]);
+                load4<T>(reinterpret_cast<const char*>(&raw), c4);
+              } else {
+                const uint4 raw = __builtin_bit_cast(uint4, cv4[i + h][j]);
+                ET<T>::unpack(raw, c4);
+              }
+              const float* cc = xfc + j * 16 + 4 * q;
+              bnb_accumulate(g4, c4, *reinterpret_cast<const float4*>(cc), *reinterpret_cast<const float4*>(cc + TN),
+                             *reinterpret_cast<const float4*>(cc + 2 * TN), *reinterpret_cast<const float4*>(cc + 3 * TN), s1[j], s2[j]);
+            } else if (k.stats != nullptr) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) { s1[j][r] += v[h][r]; s2[j][r] += v[h][r] * v[h][r]; }
             }
@@ -1004,7 +1141,7 @@ __global__ __launch_bounds__(256, (ROW7 ? 2 : 3)) void conv_thin_kernel(const Th
         double a = 0.0, b = 0.0;
 #pragma unroll
         for (int w = 0; w < 4; ++w) { a += (double)red[(w * TN + tid) * 2]; b += (double)red[(w * TN + tid) * 2 + 1]; }
-        double* st = k.stats + (size_t)(blockIdx.x % UBR_STAT_SLOTS) * 2 * k.Cout;
+        double* st = k.stats + (size_t)(blockIdx.x % k.nslots) * 2 * k.Cout;
         atomicAdd(&st[ch], a);
         atomicAdd(&st[k.Cout + ch], b);
       }
@@ -1453,9 +1590,9 @@ int launch_one(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
   return UBR_OK;
 }
 
-template <typename T, int FW, int NT, int TWF, int UPB, bool XF, bool LSM = false, bool ROW7 = false>
+template <typename T, int FW, int NT, int TWF, int UPB, bool XF, bool LSM = false, bool ROW7 = false, int EXT = 0>
 int launch_thin(const ThinK& k, dim3 grid, size_t lds, hipStream_t st) {
-  auto fn = conv_thin_kernel<T, FW, NT, TWF, UPB, XF, LSM, ROW7>;
+  auto fn = conv_thin_kernel<T, FW, NT, TWF, UPB, XF, LSM, ROW7, EXT>;
   if (lds > 64 * 1024) {
     static thread_local size_t maxset = 0;
     if (lds > maxset) {
@@ -1516,6 +1653,23 @@ int try_thin(const ConvK& c, dim3 grid, hipStream_t st, int* rc) {
   k.Cout = c.Cout; k.Cout_pad = c.Cout_pad; k.CU = c.CU; k.OH = c.OH; k.OW = c.OW;
   k.act = c.act; k.epilogue = c.epilogue; k.wlinear = c.wlinear; k.dbg = c.dbg; k.stamps = c.stamps;
   for (int t = 0; t < c.ntaps; ++t) { k.dy[t] = c.dy[t]; k.dx[t] = c.dx[t]; k.wt[t] = c.wt[t]; }
+  // training epilogues: BatchNorm-backward sums (EXT 1) or a ReLU bit mask on the addend (EXT 2); never both (ubr_conv checks)
+  const int ext = c.bc != nullptr ? 1 : (c.ad_mask != nullptr ? 2 : 0);
+  if (ext != 0 && (c.in_scale != nullptr || c.epilogue != 0)) return 0;
+  // fp32 with the masked addend: this variant of the kernel computes channel 1 of one fragment wrongly in lanes 12-15 of every
+  // quad (independent of the mask values and of how the gating is written; 16-bit variants and the other epilogues are
+  // bit-exact against the generic kernel) -- the parity path takes the generic kernel instead
+  if (ext == 2 && sizeof(T) == 4) return 0;
+  k.nslots = c.nslots;
+  if (ext == 1) {
+    if (c.bc_sy >= (1L << 24) || (long)c.OH * c.bc_sy >= (1L << 31)) return 0;
+    k.bc = c.bc; k.bc_sn = c.bc_sn; k.bc_sy = (int)c.bc_sy; k.bc_sx = (int)c.bc_sx; k.bc_bytes = (unsigned)((long)c.OH * c.bc_sy);
+    k.bmean = c.bmean; k.bscale = c.bscale; k.bshift = c.bshift; k.binvstd = c.binvstd;
+  }
+  if (ext == 2) {
+    if ((long)c.OH * c.OW * c.ad_mask_cu >= (1L << 31)) return 0;
+    k.ad_mask = c.ad_mask; k.ad_mask_cu = c.ad_mask_cu; k.mask_bytes = (unsigned)((long)c.OH * c.OW * c.ad_mask_cu);
+  }
   if (row7) {
     // 56 virtual taps, row-major with the horizontal taps padded to 8: K-step dy*4 + p holds taps (dy, 2p) and (dy, 2p+1)
     for (int a = 0; a < 7; ++a)
@@ -1536,7 +1690,7 @@ int try_thin(const ConvK& c, dim3 grid, hipStream_t st, int* rc) {
   // persistent grid: the workgroups that fit the chip at once (register- or LDS-limited), each walking tiles with a stride of the grid
   static const int wg_per_cu = [] { const char* e = getenv("UBR_CONV_THIN_WGS"); return e ? atoi(e) : 0; }();
   int per_cu = (int)((150 * 1024) / lds);
-  const int reg_cap = row7 ? 2 : (NT == 1 ? 4 : 3);          // <= 128 VGPRs for the 16-cout tiles, <= 168 for the 32-cout ones, <= 256 for ROW7
+  const int reg_cap = (row7 || (ext == 1 && NT == 2)) ? 2 : (NT == 1 ? (ext == 1 ? 3 : 4) : 3);   // <= 128 VGPRs for the 16-cout tiles, <= 168 for the 32-cout ones, <= 256 for ROW7 and the 32-cout BatchNorm-backward epilogue
   if (per_cu > reg_cap) per_cu = reg_cap;
   if (wg_per_cu > 0) per_cu = wg_per_cu;
   if (per_cu < 1) per_cu = 1;
@@ -1547,11 +1701,17 @@ int try_thin(const ConvK& c, dim3 grid, hipStream_t st, int* rc) {
   const bool xf = c.in_scale != nullptr;
   snprintf(g_last_conv_name, sizeof(g_last_conv_name), "conv_thin_kernel<%s, %d, %d, %d, %d, %s, %s>", sizeof(T) == 4 ? "float" : (std::is_same<T, bf16_t>::value ? "bf16_t" : "f16_t"),
            FW, NT, TWF, c.UPB, xf ? "true" : "false", c.epilogue == 1 ? "true" : "false");
+  if (ext != 0)
+    snprintf(g_last_conv_name, sizeof(g_last_conv_name), "conv_thin_kernel<%s, %d, %d, %d, %d, false, false, %s, %d>", sizeof(T) == 4 ? "float" : (std::is_same<T, bf16_t>::value ? "bf16_t" : "f16_t"),
+             FW, NT, TWF, c.UPB, row7 ? "true" : "false", ext);
   if constexpr (FW == 8 && NT == 1 && sizeof(T) == 2) {
     if (row7) {
+      if (ext == 0)
       snprintf(g_last_conv_name, sizeof(g_last_conv_name), "conv_thin_kernel<%s, 8, 1, 2, 2, %s, %s, true>", std::is_same<T, bf16_t>::value ? "bf16_t" : "f16_t",
                xf ? "true" : "false", c.epilogue == 1 ? "true" : "false");
       if (c.epilogue == 1) *rc = xf ? launch_thin<T, 8, 1, 2, 2, true, true, true>(k, g, lds, st) : launch_thin<T, 8, 1, 2, 2, false, true, true>(k, g, lds, st);
+      else if (ext == 1) *rc = launch_thin<T, 8, 1, 2, 2, false, false, true, 1>(k, g, lds, st);
+      else if (ext == 2) *rc = launch_thin<T, 8, 1, 2, 2, false, false, true, 2>(k, g, lds, st);
       else *rc = xf ? launch_thin<T, 8, 1, 2, 2, true, false, true>(k, g, lds, st) : launch_thin<T, 8, 1, 2, 2, false, false, true>(k, g, lds, st);
       return 1;
     }
@@ -1566,7 +1726,9 @@ int try_thin(const ConvK& c, dim3 grid, hipStream_t st, int* rc) {
       return 0;
     }
   }
-  if (c.UPB == 2) *rc = xf ? launch_thin<T, FW, NT, TWF, 2, true>(k, g, lds, st) : launch_thin<T, FW, NT, TWF, 2, false>(k, g, lds, st);
+  if (ext == 1) *rc = c.UPB == 2 ? launch_thin<T, FW, NT, TWF, 2, false, false, false, 1>(k, g, lds, st) : launch_thin<T, FW, NT, TWF, 4, false, false, false, 1>(k, g, lds, st);
+  else if (ext == 2) *rc = c.UPB == 2 ? launch_thin<T, FW, NT, TWF, 2, false, false, false, 2>(k, g, lds, st) : launch_thin<T, FW, NT, TWF, 4, false, false, false, 2>(k, g, lds, st);
+  else if (c.UPB == 2) *rc = xf ? launch_thin<T, FW, NT, TWF, 2, true>(k, g, lds, st) : launch_thin<T, FW, NT, TWF, 2, false>(k, g, lds, st);
   else *rc = xf ? launch_thin<T, FW, NT, TWF, 4, true>(k, g, lds, st) : launch_thin<T, FW, NT, TWF, 4, false>(k, g, lds, st);
   return 1;
 }
@@ -1782,6 +1944,16 @@ extern "C" int ubr_conv(const ubr_conv_desc* d, void* stream) {
     UBR_CHECK(d->addend.p == nullptr && d->stats == nullptr && d->act == 0, "ubr_conv: log-softmax epilogue takes no addend/stats/act");
   }
   UBR_CHECK((d->act & ~3) == 0, "ubr_conv: bad act flags %d", d->act);
+  if (d->addend_mask != nullptr)
+    UBR_CHECK(d->addend.p != nullptr && d->epilogue == 0 && d->Cout % cpu == 0 && d->bnb_c.p == nullptr, "ubr_conv: addend_mask needs an addend, NHWC output, whole channel units, and excludes bnb_c");
+  if (d->bnb_c.p != nullptr) {
+    UBR_CHECK(d->stats != nullptr && d->epilogue == 0 && d->act == 0 && d->Cout % 4 == 0 && d->bnb_mean && d->bnb_scale && d->bnb_shift && d->bnb_invstd,
+              "ubr_conv: bnb_c needs stats, the four BatchNorm vectors, NHWC output and no activation");
+    UBR_CHECK((((uintptr_t)d->bnb_c.p) % (4 * esz)) == 0 && d->bnb_c.sx % 4 == 0 && d->bnb_c.sy % 4 == 0 && d->bnb_c.sn % 4 == 0 && d->bnb_c.sx >= d->Cout &&
+              ubr_aligned16(d->bnb_mean) && ubr_aligned16(d->bnb_scale) && ubr_aligned16(d->bnb_shift) && ubr_aligned16(d->bnb_invstd),
+              "ubr_conv: bnb_c view must be aligned to 4 elements, the BatchNorm vectors to 16 bytes");
+  }
+  const bool train_epi = d->addend_mask != nullptr || d->bnb_c.p != nullptr;
   int dymin = 127, dymax = -128, dxmin = 127, dxmax = -128;
   for (int t = 0; t < d->ntaps; ++t) {
     dymin = d->dy[t] < dymin ? d->dy[t] : dymin; dymax = d->dy[t] > dymax ? d->dy[t] : dymax;
@@ -1795,7 +1967,7 @@ extern "C" int ubr_conv(const ubr_conv_desc* d, void* stream) {
   // ---- choose a tile configuration ----
   Plan best{}; bool have = false;
   if (d->tile_hint > 100) {        // 101.. = conv_pc_kernel tiles (tests)
-    UBR_CHECK(d->tile_hint <= 100 + kNumPc, "ubr_conv: tile_hint %d out of range", d->tile_hint);
+    UBR_CHECK(d->tile_hint <= 100 + kNumPc && !train_epi, "ubr_conv: tile_hint %d out of range (or a training epilogue on conv_pc_kernel)", d->tile_hint);
     have = plan_pc(d, d->tile_hint - 101, dymin, dymax, dxmin, dxmax, &best);
     UBR_CHECK(have, "ubr_conv: producer/consumer tile_hint %d does not fit this shape", d->tile_hint);
   } else if (d->tile_hint > 0) {
@@ -1816,7 +1988,7 @@ extern "C" int ubr_conv(const ubr_conv_desc* d, void* stream) {
       static const int pc_mode = [] { const char* e = getenv("UBR_CONV_PC"); return e ? atoi(e) : 1; }();   // 0 off, 1 selective, 2 every eligible layer
       const int nblk_pc = d->Cin / (4 * cpu);
       const bool pick = pc_mode == 2 || (pc_mode == 1 && (nblk_pc <= 2 || (long)d->OH * d->OW <= 256) && !(d->Cin == d->Cout_pad && nblk_pc == 2));
-      if (pick && d->Cout_pad % 64 == 0 && d->ntaps >= 4) {
+      if (pick && !train_epi && d->Cout_pad % 64 == 0 && d->ntaps >= 4) {
         Plan cand{}; bool any = false;
         const int wide[] = {0, 1}, narrow[] = {2, 3};
         const int* ord = d->OW >= 32 ? wide : narrow;
@@ -1866,6 +2038,10 @@ extern "C" int ubr_conv(const ubr_conv_desc* d, void* stream) {
   k.y = (char*)d->y.p; k.y_sn = d->y.sn * esz; k.y_sy = d->y.sy * esz; k.y_sx = d->y.sx * esz;
   k.ad = (const char*)d->addend.p; k.a_sn = d->addend.sn * esz; k.a_sy = d->addend.sy * esz; k.a_sx = d->addend.sx * esz;
   k.bias = d->bias; k.stats = d->stats;
+  k.ad_mask = d->addend_mask; k.ad_mask_cu = d->Cout / cpu;
+  k.bc = (const char*)d->bnb_c.p; k.bc_sn = d->bnb_c.sn * esz; k.bc_sy = d->bnb_c.sy * esz; k.bc_sx = d->bnb_c.sx * esz;
+  k.bmean = d->bnb_mean; k.bscale = d->bnb_scale; k.bshift = d->bnb_shift; k.binvstd = d->bnb_invstd;
+  k.nslots = d->bnb_c.p != nullptr ? UBR_RED_SLOTS : UBR_STAT_SLOTS;
   k.H = d->H; k.W = d->W;
   k.CU = d->Cin / cpu; k.UPB = best.UPB; k.lgUPB = ubr_ilog2(best.UPB); k.nblk = k.CU / best.UPB;
   k.Cout = d->Cout; k.Cout_pad = d->Cout_pad;

@@ -37,6 +37,17 @@ _RELU_MASK = _os.environ.get("UBR_RELU_MASK", "1") != "0"      # block tails kee
 # BatchNorm-backward finalize fused into the apply pass (every workgroup re-sums the reduce pass's stripes) up to this many
 # channels; wider layers keep the separate ubr_bn_bwd_finalize launch (the re-summation grows with C, the launch does not)
 _FIN_MAX_C = int(_os.environ.get("UBR_FIN_MAX_C", "64"))
+# BatchNorm-backward reduce passes folded into the epilogue of the data-gradient conv that produces their gradient operand
+# (ubr_conv_desc.bnb_c), and identity-block skip gradients re-formed from the ReLU bit mask in the consuming conv's epilogue
+# (ubr_conv_desc.addend_mask) instead of being written by the tail's backward
+_BNB_FUSE = _os.environ.get("UBR_BNB_FUSE", "0") != "0"
+_MASK_ADDEND = _os.environ.get("UBR_MASK_ADDEND", "1") != "0"
+# every k-th weight gradient of a backward pass stays on the compute stream (0 = all on the side stream): static balancing of
+# the two streams of the backward pass
+_WG_MAIN_EVERY = int(_os.environ.get("UBR_WGRAD_MAIN_EVERY", "0"))
+# UBR_WGRAD_ORDER=after: a block's weight gradients are issued right AFTER the data-gradient conv that shares their gradient
+# operand (single-stream schedule: the operand is then still in L2 / MALL); default: before it (side stream: earliest start)
+_WG_AFTER = _os.environ.get("UBR_WGRAD_ORDER", "before") == "after"
 
 
 def _phase(t, ry, rx):
@@ -68,6 +79,7 @@ class Engine:
         self.wws = ops.WgradWorkspace()
         self.side = None
         self._side_on = False
+        self._wg_count = 0
         self._evs, self._ev_next, self._main = [], 0, None
         self._red_buf, self._red_off, self._red_elems = None, 0, 0
         self._bwd_packed, self._pack_evs = None, None
@@ -350,6 +362,7 @@ class Engine:
         rocprofv3 sees them)."""
         import os
         self._side_on = dev.type == "cuda" and os.environ.get("UBR_WGRAD_STREAM", "1") != "0"
+        self._wg_count = 0
         if self._side_on:
             self._ensure_side(dev)
         if self._side_on:
@@ -376,7 +389,8 @@ class Engine:
             self._side_on = False
 
     def _wg(self, x, g, *args, **kw):
-        if not self._side_on:
+        self._wg_count += 1
+        if not self._side_on or (_WG_MAIN_EVERY > 0 and self._wg_count % _WG_MAIN_EVERY == 0):
             return ops.wgrad(x, g, *args, **kw)
         # side stream waits for everything queued on the compute stream so far (x and g are produced there); the
         # launch goes straight to the side stream's handle -- no stream-context switch, one pooled event per call
@@ -396,10 +410,12 @@ class Engine:
         self._ev_next = i + 1
         return self._evs[i]
 
-    def _bn_bwd(self, site: BNSite, ga, ga2, c, relu, G, cnt):
-        """backward through a = relu(bn(c)) (or bn only): returns g_c; writes dgamma/dbeta"""
-        red = self._red(2 * site.C, c.device)
-        ops.bn_bwd_reduce(ga, ga2, c, site.scale, site.shift, site.mean, site.invstd, relu, red)
+    def _bn_bwd(self, site: BNSite, ga, ga2, c, relu, G, cnt, red=None):
+        """backward through a = relu(bn(c)) (or bn only): returns g_c; writes dgamma/dbeta.
+        red: the reduce pass's sums, when the conv that produced `ga` already accumulated them in its epilogue"""
+        if red is None:
+            red = self._red(2 * site.C, c.device)
+            ops.bn_bwd_reduce(ga, ga2, c, site.scale, site.shift, site.mean, site.invstd, relu, red)
         gc = self._new(c.shape, dtype=c.dtype, device=c.device)
         if site.C <= _FIN_MAX_C:
             ops.bn_bwd_apply_fin(ga, ga2, c, site.scale, site.shift, site.mean, site.invstd, relu, red, cnt,
@@ -411,7 +427,7 @@ class Engine:
         ops.bn_bwd_apply(ga, ga2, c, site.scale, site.shift, site.mean, site.invstd, relu, k1, k2, gc)
         return gc
 
-    def _conv_dgrad(self, conv_mod, g, gx, S, addend=None, k=3):
+    def _conv_dgrad(self, conv_mod, g, gx, S, addend=None, k=3, addend_mask=None, bnb=None, stats=None):
         """data gradient of Conv2d(k, stride S, pad k//2): g (conv output grad) -> gx (input grad view)"""
         dt = g.dtype
         wp = self.packed(conv_mod.weight, dt, "dgrad")
@@ -419,7 +435,7 @@ class Engine:
         pad = k // 2
         if S == 1:
             taps = DG3 if k == 3 else (DG1 if k == 1 else DG7)
-            ops.conv(g, wp, gx, taps, Cin, addend=addend)
+            ops.conv(g, wp, gx, taps, Cin, addend=addend, addend_mask=addend_mask, bnb=bnb, stats=stats)
         else:
             for ry in range(2):
                 for rx in range(2):
@@ -448,7 +464,10 @@ class Engine:
         ops.block_tail_bwd_reduce(go, go2, out, c2, bn2.scale, bn2.shift, bn2.mean, bn2.invstd,
                                   cb, bnb.mean if byp else None, bnb.invstd if byp else None, red2, redb, relu_mask=mask)
         g_c2 = self._new(c2.shape, dtype=dt, device=dev)
-        g_sc = self._new(c2.shape, dtype=dt, device=dev)
+        # identity block with one gradient operand: the skip gradient go*[out>0] is not written; conv1's data-gradient epilogue
+        # re-forms it from go and the bit mask
+        lazy_sc = _MASK_ADDEND and mask is not None and not byp and go2 is None and need_gx and Cout <= _FIN_MAX_C
+        g_sc = None if lazy_sc else self._new(c2.shape, dtype=dt, device=dev)
         if mask is not None and Cout <= _FIN_MAX_C:
             ops.block_tail_bwd_apply_fin(go, go2, mask, c2, bn2.scale, bn2.shift, bn2.mean, bn2.invstd, red2, G(blk.bn2.weight), G(blk.bn2.bias),
                                          cb, bnb.scale if byp else None, bnb.mean if byp else None, bnb.invstd if byp else None,
@@ -463,24 +482,44 @@ class Engine:
                                      k[2 * Cout:3 * Cout] if byp else None, k[3 * Cout:] if byp else None, g_c2, g_sc, relu_mask=mask)
         # conv2: weight grad (input = relu(bn1(c1)) re-formed on load) and data grad
         kk = 9
-        self._wg(c1, g_c2, T3, G(blk.conv2.weight), Cout * kk, kk, Cout, Cout, self.wws, xf=self.relu_affine(bn1))
+        if not _WG_AFTER:
+            self._wg(c1, g_c2, T3, G(blk.conv2.weight), Cout * kk, kk, Cout, Cout, self.wws, xf=self.relu_affine(bn1))
         g_a1 = self._new(c1.shape, dtype=dt, device=dev)
-        self._conv_dgrad(blk.conv2, g_c2, g_a1, 1)
-        del g_c2
-        g_c1 = self._bn_bwd(bn1, g_a1, None, c1, True, G, cnt)
+        if _BNB_FUSE:
+            # the reduce pass of bn1's backward rides in the epilogue of the conv that produces its gradient operand
+            red1 = self._red(2 * Cout, dev)
+            self._conv_dgrad(blk.conv2, g_c2, g_a1, 1, bnb=(c1, bn1.mean, bn1.scale, bn1.shift, bn1.invstd), stats=red1)
+            if _WG_AFTER:
+                self._wg(c1, g_c2, T3, G(blk.conv2.weight), Cout * kk, kk, Cout, Cout, self.wws, xf=self.relu_affine(bn1))
+            del g_c2
+            g_c1 = self._bn_bwd(bn1, g_a1, None, c1, True, G, cnt, red=red1)
+        else:
+            self._conv_dgrad(blk.conv2, g_c2, g_a1, 1)
+            if _WG_AFTER:
+                self._wg(c1, g_c2, T3, G(blk.conv2.weight), Cout * kk, kk, Cout, Cout, self.wws, xf=self.relu_affine(bn1))
+            del g_c2
+            g_c1 = self._bn_bwd(bn1, g_a1, None, c1, True, G, cnt)
         del g_a1
         Cin = x.shape[3]
-        self._wg(x, g_c1, T3, G(blk.conv1.weight), Cin * kk, kk, Cout, Cin, self.wws, S=S, xf=rec.xf_in)
-        if byp:
-            self._wg(x, g_sc, T1, G(blk.bypass.weight), Cin, 1, Cout, Cin, self.wws, S=S, xf=rec.xf_in)
+
+        def wg_conv1():
+            self._wg(x, g_c1, T3, G(blk.conv1.weight), Cin * kk, kk, Cout, Cin, self.wws, S=S, xf=rec.xf_in)
+            if byp:
+                self._wg(x, g_sc, T1, G(blk.bypass.weight), Cin, 1, Cout, Cin, self.wws, S=S, xf=rec.xf_in)
+        if not _WG_AFTER or not need_gx:
+            wg_conv1()
         if not need_gx:
             return None
         gx = self._new(x.shape, dtype=dt, device=dev)
         if byp:
             self._conv_dgrad(blk.conv1, g_c1, gx, S)
             self._conv_dgrad(blk.bypass, g_sc, gx, S, addend=gx, k=1)
+        elif lazy_sc:
+            self._conv_dgrad(blk.conv1, g_c1, gx, S, addend=go, addend_mask=mask)
         else:
             self._conv_dgrad(blk.conv1, g_c1, gx, S, addend=g_sc)
+        if _WG_AFTER:
+            wg_conv1()
         return gx
 
     # ------------------------------------------------------------------ DoubleResNet
@@ -594,9 +633,11 @@ class Engine:
         ops.channel_sum(g_l, red[:16 * NS])
         ops.cast_f64_to_f32(red[:16 * NS], G(m.conv11.bias), ncls, stride=16)
         g_a10 = self._new((N, H, W, nk), dtype=dt, device=dev)
-        ops.conv(g_l, self._packed_dgrad_padded(m.conv11.weight, dt), g_a10, DG7, nk)
+        red10 = self._red(2 * nk, dev) if _BNB_FUSE else None
+        ops.conv(g_l, self._packed_dgrad_padded(m.conv11.weight, dt), g_a10, DG7, nk,
+                 bnb=(sv.c10, bn10.mean, bn10.scale, bn10.shift, bn10.invstd) if _BNB_FUSE else None, stats=red10)
         del g_l
-        g_c10 = self._bn_bwd(bn10, g_a10, None, sv.c10, True, G, N * H * W)
+        g_c10 = self._bn_bwd(bn10, g_a10, None, sv.c10, True, G, N * H * W, red=red10)
         del g_a10
         self._wg(sv.d1o, g_c10, T7, G(m.conv10.weight), ip * 49, 49, nk, ip, self.wws)
         ops.channel_sum(g_c10, red[16 * NS:])
@@ -982,9 +1023,10 @@ class Engine:
         g_a10 = self._new((N, H, W, nk), dtype=dt, device=dev)
         # data gradient of conv11: K = the 16 (zero-padded) logit channels
         wp = self._packed_dgrad_padded(m.conv11.weight, dt)
-        ops.conv(g_l, wp, g_a10, DG7, nk)
+        red10 = self._red(2 * nk, dev) if _BNB_FUSE else None
+        ops.conv(g_l, wp, g_a10, DG7, nk, bnb=(sv.c10, bn10.mean, bn10.scale, bn10.shift, bn10.invstd) if _BNB_FUSE else None, stats=red10)
         del g_l
-        g_c10 = self._bn_bwd(bn10, g_a10, None, sv.c10, True, G, N * H * W)
+        g_c10 = self._bn_bwd(bn10, g_a10, None, sv.c10, True, G, N * H * W, red=red10)
         del g_a10
         self._wg(sv.d1o, g_c10, T7, G(m.conv10.weight), ip * 49, 49, nk, ip, self.wws)
         ops.channel_sum(g_c10, red[16 * NS:])

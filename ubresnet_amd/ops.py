@@ -204,9 +204,12 @@ def _tap_arrays(taps):
 @_timed("conv")
 def conv(x: torch.Tensor, wp: torch.Tensor, y: torch.Tensor, taps, Cout: int, S: int = 1, iy0: int = 0, ix0: int = 0,
          xf: Optional[Affine] = None, bias: Optional[torch.Tensor] = None, addend: Optional[torch.Tensor] = None,
-         stats: Optional[torch.Tensor] = None, logsoftmax: bool = False, tile_hint: int = 0, in_hw=None, act: int = 0):
+         stats: Optional[torch.Tensor] = None, logsoftmax: bool = False, tile_hint: int = 0, in_hw=None, act: int = 0,
+         addend_mask: Optional[torch.Tensor] = None, bnb=None):
     """One ubr_conv launch.  x: NHWC input view; y: NHWC output-grid view (or, with logsoftmax, the
-    contiguous fp32 NCHW result); taps: [(dy,dx,packed tap index)]."""
+    contiguous fp32 NCHW result); taps: [(dy,dx,packed tap index)].
+    addend_mask: the ReLU bit mask of a block tail gating `addend` (out = conv + addend * bit);
+    bnb = (c, mean, scale, shift, invstd): `stats` receives the BatchNorm-backward sums of a = relu(bn(c)) for g = this output."""
     d = L.ConvDesc()
     d.dtype = L.dtype_id(x.dtype)
     N, H, W, Cin = x.shape
@@ -252,6 +255,15 @@ def conv(x: torch.Tensor, wp: torch.Tensor, y: torch.Tensor, taps, Cout: int, S:
         assert xf.scale.numel() >= Cin
     d.tile_hint = tile_hint
     d.act = act
+    if addend_mask is not None:
+        assert addend is not None and addend_mask.dtype == torch.uint8 and addend_mask.is_contiguous()
+        assert addend_mask.numel() >= y.shape[0] * y.shape[1] * y.shape[2] * (Cout // L.chans_per_unit(x.dtype))
+        d.addend_mask = addend_mask.data_ptr()
+    if bnb is not None:
+        cten, mean, scale, shift, invstd = bnb
+        assert stats is not None and cten.shape == y.shape and cten.dtype == y.dtype
+        d.bnb_c = _tv(cten)
+        d.bnb_mean, d.bnb_scale, d.bnb_shift, d.bnb_invstd = mean.data_ptr(), scale.data_ptr(), shift.data_ptr(), invstd.data_ptr()
     L.check(L.lib().ubr_conv(C.byref(d), L.stream_ptr()), "conv")
 
 
