@@ -317,7 +317,28 @@ def infer_leg(events=6, warmup=2):
     nt = seg.tiles_per_event
     gb_tile = 0.654e9        # 201.2 M elements per 512^2 image x (512*832 / 512^2) x 2 B
     ach = gb_tile * nt * events / el / 1e9
-    return {"metric": "tiles/sec, whole-view 3456x1008 tiled inference (512x832 tiles, forward only, fp16, hipGraph)",
+    # per-kernel breakdown of ONE forward of the 30-tile batch (a timed replay of the recorded launch tape: HIP events around every
+    # launch; the timed events above replay the captured hipGraph of the same launches)
+    tops = dominant = None
+    ktime = None
+    try:
+        from ubresnet_amd import ops, plan as _plan
+        prof = ops.LaunchProfiler()
+        ops._prof = prof
+        _plan.TIMED = prof.timed if _plan.ENABLED else None
+        try:
+            with torch.no_grad():
+                seg._forward_batch(seg._static_in)
+            torch.cuda.synchronize()
+        finally:
+            ops._prof = None
+            _plan.TIMED = None
+        dominant, tops, tot, _ = _rooflines(prof, "f16")
+        ktime = 1e3 * tot
+    except Exception as e:
+        tops = {"error": repr(e)}
+    return {"roofline_top_kernels": tops, "roofline_dominant_kernel": dominant, "kernel_time_ms_per_event": ktime,
+            "metric": "tiles/sec, whole-view 3456x1008 tiled inference (512x832 tiles, forward only, fp16, hipGraph)",
             "value": nt * events / el, "unit": "tiles/sec", "events_per_sec": events / el, "ms_per_event": 1e3 * el / events,
             "tiles_per_event": nt, "events_timed": events, "dtype": "f16", "hipgraph": True, "n_gpus": 1, "data": "synthetic",
             "config": {"workload": "UResNet ip16 4-class eval, 3x1008x3456 views -> 30 tiles of 512x832, one graph replay of 30 tiles"},

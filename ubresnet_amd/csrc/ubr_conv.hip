@@ -14,6 +14,7 @@
 // Workgroup = 256 threads = 4 waves.  Tile = TH x TW output pixels (TW = 16*TWF) x TN = 16*NT
 // output channels.  Wave w owns FW pixel fragments (16 px each) x NT channel fragments.
 #include <stdlib.h>
+#include <type_traits>
 #include "ubr_common.h"
 #include "ubr_host.h"
 
@@ -46,6 +47,7 @@ struct ConvK {
   const char* bc; long bc_sn, bc_sy, bc_sx;      // saved activation c of the BatchNorm-backward sums (view of the output grid)
   const float *bmean, *bscale, *bshift, *binvstd;
   int nslots;                                    // stripes of `stats` in use
+  int pair_store;                                // conv_igemm_kernel: 16-byte stores of fragment pairs
   int8_t dy[UBR_MAX_TAPS], dx[UBR_MAX_TAPS];
   uint8_t wt[UBR_MAX_TAPS];
   unsigned long long* stamps;                    // diagnostic build (-DUBR_CONV_STAMPS): per-workgroup phase cycle sums
@@ -119,9 +121,58 @@ __device__ __forceinline__ void bnb_accumulate(const float* g, const float* c, c
 // CU to two (37 vs 32 us), the wide layers do not change -- so 4-unit blocks keep 80 B.
 __host__ __device__ constexpr int conv_pixb(int upb) { return upb == 2 ? 32 : upb * 16 + 16; }
 
+// conv_thin_kernel, 4-unit blocks: -DUBR_THIN_PIXB4=96 selects the conflict-free 96-byte pixel stride (with the halo region
+// sized to the halo exactly, three workgroups still fit a CU).  Measured against the 80-byte stride, same box: 32 -> 32 channels
+// at 256^2 43 us either way, train step 11.71 vs 11.69 ms -- the 2-way conflict on the pixel-fragment reads is not what bounds
+// this kernel.  Default: 80 bytes (less LDS).
+#ifndef UBR_THIN_PIXB4
+#define UBR_THIN_PIXB4 80
+#endif
+__host__ __device__ constexpr int thin_pixb(int upb) { return upb == 4 ? UBR_THIN_PIXB4 : conv_pixb(upb); }
+
 // register slots of the cin-block pipeline (PIPE): one block's halo and weight items per thread, sized for 3x3 taps
 __host__ __device__ constexpr int conv_pipe_hslots(int fw, int twf) { return ((4 * fw / twf + 2) * (twf * 16 + 2) * 4 + 255) / 256; }
 __host__ __device__ constexpr int conv_pipe_wslots(int nt) { return (36 * nt * 16 + 255) / 256; }
+
+// Two pixel fragments' 4-channel groups (fp32) -> this lane's 16 output bytes after the quad exchange (see store_pair16).
+// bf16: converts and swaps in ONE asm statement with early-clobber outputs, so that no convert's destination is a source of
+// its neighbours.  hipcc allocated  v35 <- cvt(v36,v37); v36 <- cvt(v30,v31); v37 <- cvt(...)  back to back, and on gfx950
+// the second convert's result then came out wrong in lanes 12-15 of every row (channels 2-3 / 10-11 of every second pixel
+// row; the f16 build, whose registers happened not to overlap, was correct).  Wait states by hand: hipcc pads nothing in asm.
+template <typename T> __device__ __forceinline__ uint4 pack_swap_pair(const float* v0, const float* v1);
+template <> __device__ __forceinline__ uint4 pack_swap_pair<bf16_t>(const float* v0, const float* v1) {
+  uint2 X, Y;
+  asm volatile("v_cvt_pk_bf16_f32 %0, %4, %5\n\tv_cvt_pk_bf16_f32 %1, %6, %7\n\tv_cvt_pk_bf16_f32 %2, %8, %9\n\t"
+               "v_cvt_pk_bf16_f32 %3, %10, %11\n\ts_nop 1\n\tv_permlane16_swap_b32 %0, %2\n\tv_permlane16_swap_b32 %1, %3\n\ts_nop 3"
+               : "=&v"(X.x), "=&v"(X.y), "=&v"(Y.x), "=&v"(Y.y)
+               : "v"(v0[0]), "v"(v0[1]), "v"(v0[2]), "v"(v0[3]), "v"(v1[0]), "v"(v1[1]), "v"(v1[2]), "v"(v1[3]));
+  return make_uint4(X.x, X.y, Y.x, Y.y);
+}
+template <> __device__ __forceinline__ uint4 pack_swap_pair<f16_t>(const float* v0, const float* v1) {
+  f16x4_t a, b;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { a[r] = (_Float16)v0[r]; b[r] = (_Float16)v1[r]; }
+  uint2 X = __builtin_bit_cast(uint2, a), Y = __builtin_bit_cast(uint2, b);
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 3" : "+v"(X.x), "+v"(Y.x), "+v"(X.y), "+v"(Y.y));
+  return make_uint4(X.x, X.y, Y.x, Y.y);
+}
+template <> __device__ __forceinline__ uint4 pack_swap_pair<float>(const float* v0, const float* v1) { return make_uint4(0u, 0u, 0u, 0u); }
+
+// 16-bit types: lane (q, l16) holds channels 4q..4q+3 of pixel l16 of fragment 0 (X) and of fragment 1 (Y), 8 bytes each.
+// v_permlane16_swap exchanges the odd quads of X with the even quads of Y: afterwards an even quad holds channels
+// 4q..4q+7 of its fragment-0 pixel and an odd quad channels 4(q-1)..4q+3 of its fragment-1 pixel -- 16 contiguous bytes.
+// p0 / p1 address channel 4q of the lane's pixel in fragment 0 / 1.
+template <typename T> __device__ __forceinline__ void store_frag_pair(char* p0, char* p1, bool ok0, bool ok1, const float* v0, const float* v1, int q) {
+  if constexpr (std::is_same<T, float>::value) {
+    if (ok0) store4<float>(p0, v0);
+    if (ok1) store4<float>(p1, v1);
+  } else {
+    const uint4 v = pack_swap_pair<T>(v0, v1);
+    const bool odd = (q & 1) != 0;
+    char* p = odd ? (p1 - 8) : p0;          // an odd quad's 16 bytes start one quad (4 channels) lower
+    if (odd ? ok1 : ok0) *reinterpret_cast<uint4*>(p) = v;
+  }
+}
 
 template <typename T, int FW, int NT, int TWF, bool PIPE>
 __global__ __launch_bounds__(256, ((NT == 4 && FW <= 2 && !PIPE) ? 4 : 2)) void conv_igemm_kernel(const ConvK k) {
@@ -472,12 +523,11 @@ __global__ __launch_bounds__(256, ((NT == 4 && FW <= 2 && !PIPE) ? 4 : 2)) void 
       bmu = *reinterpret_cast<const float4*>(k.bmean + ch); bsc = *reinterpret_cast<const float4*>(k.bscale + ch);
       bsh = *reinterpret_cast<const float4*>(k.bshift + ch); bis = *reinterpret_cast<const float4*>(k.binvstd + ch);
     }
-#pragma unroll
-    for (int i = 0; i < FW; ++i) {
+    // one fragment's 4-channel group: bias, activations, (masked) addend, statistics
+    auto finish = [&](int i, float* v, int& oy, int& ox) -> bool {
       const int f = wave * FW + i;
-      const int oy = oy0 + f / TWF, ox = ox0 + (f % TWF) * 16 + l16;
+      oy = oy0 + f / TWF; ox = ox0 + (f % TWF) * 16 + l16;
       const bool valid = (oy < k.OH) && (ox < k.OW);
-      float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bs[j][r];
       if (k.act & 1) {
@@ -512,6 +562,28 @@ __global__ __launch_bounds__(256, ((NT == 4 && FW <= 2 && !PIPE) ? 4 : 2)) void 
           for (int r = 0; r < 4; ++r) { s1[j][r] += v[r]; s2[j][r] += v[r] * v[r]; }
         }
       }
+      return valid;
+    };
+    // 16-bit outputs with whole, 16-byte aligned channel octets: two pixel fragments exchange half their channels
+    // (v_permlane16_swap) and every lane stores 16 bytes -- half the store instructions of the 8-byte form, which split every
+    // 128-byte line of the output into sixteen pieces
+    constexpr bool PAIRS = (FW % 2 == 0) && sizeof(T) == 2;
+    if (PAIRS && k.pair_store && k.epilogue == 0) {
+#pragma unroll
+      for (int i = 0; i < FW; i += 2) {
+        float v0[4], v1[4];
+        int oy_a, ox_a, oy_b, ox_b;
+        const bool ok0 = finish(i, v0, oy_a, ox_a) && ch < k.Cout;
+        const bool ok1 = finish(i + (FW > 1 ? 1 : 0), v1, oy_b, ox_b) && ch < k.Cout;
+        store_frag_pair<T>(k.y + (long)n * k.y_sn + (long)oy_a * k.y_sy + (long)ox_a * k.y_sx + (long)ch * ESZ,
+                           k.y + (long)n * k.y_sn + (long)oy_b * k.y_sy + (long)ox_b * k.y_sx + (long)ch * ESZ, ok0, ok1, v0, v1, q);
+      }
+    } else {
+#pragma unroll
+    for (int i = 0; i < FW; ++i) {
+      float v[4];
+      int oy, ox;
+      const bool valid = finish(i, v, oy, ox);
       if (k.epilogue == 0) {
         if (valid && ch < k.Cout)
           store4<T>(k.y + (long)n * k.y_sn + (long)oy * k.y_sy + (long)ox * k.y_sx + (long)ch * ESZ, v);
@@ -535,6 +607,7 @@ __global__ __launch_bounds__(256, ((NT == 4 && FW <= 2 && !PIPE) ? 4 : 2)) void 
             if (ch + r < k.Cout) o[(((long)n * k.Cout + ch + r) * k.OH + oy) * k.OW + ox] = v[r] - lse;
         }
       }
+    }
     }
   }
 
@@ -589,46 +662,6 @@ __global__ __launch_bounds__(256, ((NT == 4 && FW <= 2 && !PIPE) ? 4 : 2)) void 
 //   * <= 128 VGPRs: four workgroups per CU alone, and two beside the 240-VGPR weight-gradient kernels of the side stream
 //     (the 165-VGPR kernel dropped to ONE workgroup per CU there).
 // ---------------------------------------------------------------------------------------------
-// Two pixel fragments' 4-channel groups (fp32) -> this lane's 16 output bytes after the quad exchange (see store_pair16).
-// bf16: converts and swaps in ONE asm statement with early-clobber outputs, so that no convert's destination is a source of
-// its neighbours.  hipcc allocated  v35 <- cvt(v36,v37); v36 <- cvt(v30,v31); v37 <- cvt(...)  back to back, and on gfx950
-// the second convert's result then came out wrong in lanes 12-15 of every row (channels 2-3 / 10-11 of every second pixel
-// row; the f16 build, whose registers happened not to overlap, was correct).  Wait states by hand: hipcc pads nothing in asm.
-template <typename T> __device__ __forceinline__ uint4 pack_swap_pair(const float* v0, const float* v1);
-template <> __device__ __forceinline__ uint4 pack_swap_pair<bf16_t>(const float* v0, const float* v1) {
-  uint2 X, Y;
-  asm volatile("v_cvt_pk_bf16_f32 %0, %4, %5\n\tv_cvt_pk_bf16_f32 %1, %6, %7\n\tv_cvt_pk_bf16_f32 %2, %8, %9\n\t"
-               "v_cvt_pk_bf16_f32 %3, %10, %11\n\ts_nop 1\n\tv_permlane16_swap_b32 %0, %2\n\tv_permlane16_swap_b32 %1, %3\n\ts_nop 3"
-               : "=&v"(X.x), "=&v"(X.y), "=&v"(Y.x), "=&v"(Y.y)
-               : "v"(v0[0]), "v"(v0[1]), "v"(v0[2]), "v"(v0[3]), "v"(v1[0]), "v"(v1[1]), "v"(v1[2]), "v"(v1[3]));
-  return make_uint4(X.x, X.y, Y.x, Y.y);
-}
-template <> __device__ __forceinline__ uint4 pack_swap_pair<f16_t>(const float* v0, const float* v1) {
-  f16x4_t a, b;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) { a[r] = (_Float16)v0[r]; b[r] = (_Float16)v1[r]; }
-  uint2 X = __builtin_bit_cast(uint2, a), Y = __builtin_bit_cast(uint2, b);
-  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 3" : "+v"(X.x), "+v"(Y.x), "+v"(X.y), "+v"(Y.y));
-  return make_uint4(X.x, X.y, Y.x, Y.y);
-}
-template <> __device__ __forceinline__ uint4 pack_swap_pair<float>(const float* v0, const float* v1) { return make_uint4(0u, 0u, 0u, 0u); }
-
-// 16-bit types: lane (q, l16) holds channels 4q..4q+3 of pixel l16 of fragment 0 (X) and of fragment 1 (Y), 8 bytes each.
-// v_permlane16_swap exchanges the odd quads of X with the even quads of Y: afterwards an even quad holds channels
-// 4q..4q+7 of its fragment-0 pixel and an odd quad channels 4(q-1)..4q+3 of its fragment-1 pixel -- 16 contiguous bytes.
-// p0 / p1 address channel 4q of the lane's pixel in fragment 0 / 1.
-template <typename T> __device__ __forceinline__ void store_frag_pair(char* p0, char* p1, bool ok0, bool ok1, const float* v0, const float* v1, int q) {
-  if constexpr (std::is_same<T, float>::value) {
-    if (ok0) store4<float>(p0, v0);
-    if (ok1) store4<float>(p1, v1);
-  } else {
-    const uint4 v = pack_swap_pair<T>(v0, v1);
-    const bool odd = (q & 1) != 0;
-    char* p = odd ? (p1 - 8) : p0;          // an odd quad's 16 bytes start one quad (4 channels) lower
-    if (odd ? ok1 : ok0) *reinterpret_cast<uint4*>(p) = v;
-  }
-}
-
 typedef __attribute__((ext_vector_type(2))) unsigned ubr_u2;
 
 struct ThinK {
@@ -674,7 +707,7 @@ __global__ __launch_bounds__(256, ((ROW7 || (EXT == 1 && NT == 2)) ? 2 : 3)) voi
   constexpr int CPU = ET<T>::CPU;
   constexpr int ESZ = 16 / CPU;
   constexpr int LG = UPB == 4 ? 2 : (UPB == 2 ? 1 : 0);
-  constexpr int PIXB = conv_pixb(UPB);        // LDS bytes per halo pixel (conflict-free fragment reads: see conv_pixb)
+  constexpr int PIXB = thin_pixb(UPB);        // LDS bytes per halo pixel (conflict-free fragment reads: see conv_pixb / thin_pixb)
   constexpr int HS = ROW7 ? 7 : (UPB == 4 ? 6 : 5);        // halo register slots per thread (host: nitems <= 256*HS)
   constexpr int PPS = 256 / UPB;              // halo pixels covered by one slot of the whole workgroup
   constexpr int WB = 4;                       // weight items per thread and batch
@@ -887,7 +920,7 @@ __global__ __launch_bounds__(256, ((ROW7 || (EXT == 1 && NT == 2)) ? 2 : 3)) voi
           v = ET<T>::pack(f);
         }
       }
-      *reinterpret_cast<uint4*>(halo_w + u * (PPS * PIXB)) = v;
+      if (tid + u * 256 < k.nitems) *reinterpret_cast<uint4*>(halo_w + u * (PPS * PIXB)) = v;     // (the region holds the halo exactly)
     }
     UBR_TSTAMP(tS);
     __syncthreads();
@@ -1680,16 +1713,18 @@ int try_thin(const ConvK& c, dim3 grid, hipStream_t st, int* rc) {
     k.nunits = 56 * 2; k.steps = 28; k.wlinear = 0;
   }
   // LDS: tap-offset + weight-source tables | weight slab | halo (HS slots of the whole workgroup) | statistics scratch
-  const int pixb = conv_pixb(c.UPB);
+  const int pixb = thin_pixb(c.UPB);
   size_t off = ((size_t)2 * 16 * k.steps + 15) & ~(size_t)15;
   k.wl_off = (int)off; off += (size_t)4 * k.steps * TN * 16;
-  k.halo_off = (int)off; off += (size_t)HSn * (256 / c.UPB) * pixb;
+  // (sized to the halo exactly: slots that reach past it are not written)
+  k.halo_off = (int)off; off += ((size_t)c.HH * c.HW * pixb + 15) & ~(size_t)15;
   k.red_off = (int)off; off += (size_t)4 * TN * 2 * sizeof(float) + (size_t)4 * 4 * 8 * sizeof(float);   // + BatchNorm-on-load constants
   const size_t lds = off;
   if (lds > 150 * 1024) return 0;
+  const size_t lds_budget = 159 * 1024;
   // persistent grid: the workgroups that fit the chip at once (register- or LDS-limited), each walking tiles with a stride of the grid
   static const int wg_per_cu = [] { const char* e = getenv("UBR_CONV_THIN_WGS"); return e ? atoi(e) : 0; }();
-  int per_cu = (int)((150 * 1024) / lds);
+  int per_cu = (int)(lds_budget / lds);
   const int reg_cap = (row7 || (ext == 1 && NT == 2)) ? 2 : (NT == 1 ? (ext == 1 ? 3 : 4) : 3);   // <= 128 VGPRs for the 16-cout tiles, <= 168 for the 32-cout ones, <= 256 for ROW7 and the 32-cout BatchNorm-backward epilogue
   if (per_cu > reg_cap) per_cu = reg_cap;
   if (wg_per_cu > 0) per_cu = wg_per_cu;
@@ -2071,6 +2106,7 @@ extern "C" int ubr_conv(const ubr_conv_desc* d, void* stream) {
   k.dbg = 0; k.stamps = nullptr;
 #endif
   k.wide_store = wide_ok ? 1 : 0;
+  { static const bool pairs = [] { const char* e = getenv("UBR_CONV_PAIRS"); return e && atoi(e) != 0; }(); k.pair_store = (wide_ok && pairs) ? 1 : 0; }
   for (int t = 0; t < d->ntaps; ++t) { k.dy[t] = d->dy[t]; k.dx[t] = d->dx[t]; k.wt[t] = d->wt[t]; }
 
   TileCfg c{};

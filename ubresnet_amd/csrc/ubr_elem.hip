@@ -584,55 +584,71 @@ struct PoolK {
   uint8_t* amax;          // [N][OH][OW][C] tap index (ky*3+kx) of the window maximum: written by forward, read by backward
 };
 
-template <typename T>
+// forward: one thread per pooled pixel and channel unit.  All nine window loads are issued before the first compare (buffer
+// loads; a tap outside the image gets an out-of-range offset and is excluded from the maximum by its validity bit), where the
+// first form walked the taps with a branch and a 64-bit address computation per tap and ran at 2 TB/s.
+template <typename T, int S, bool XF, bool AMAX, bool XCOPY>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const PoolK k) {
   constexpr int CPU = ET<T>::CPU;
+  constexpr unsigned ESZ = 16 / CPU;
   UnitIdx<T> ix(k.CU);
-  const bool xf = k.scale != nullptr;
-  float sc[CPU], sh[CPU], lo[CPU], sb[CPU];
-  if (xf) { ldconst<CPU>(k.scale, ix.c, sc); ldconst<CPU>(k.shift, ix.c, sh); ldconst<CPU>(k.lo, ix.c, lo); ldconst<CPU>(k.sub, ix.c, sb); }
+  float sc[XF ? CPU : 1], sh[XF ? CPU : 1], lo[XF ? CPU : 1], sb[XF ? CPU : 1];
+  if constexpr (XF) { ldconst<CPU>(k.scale, ix.c, sc); ldconst<CPU>(k.shift, ix.c, sh); ldconst<CPU>(k.lo, ix.c, lo); ldconst<CPU>(k.sub, ix.c, sb); }
   const long npix = (long)k.N * k.OH * k.OW;
-#pragma unroll 2
+  const long npix_in = (long)k.N * k.H * k.W;
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(k.x), 0, (int)(npix_in * k.x_ps * ESZ), 0x00020000);
+  const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(k.pooled, 0, (int)(npix * k.p_ps * ESZ), 0x00020000);
+  const __amdgpu_buffer_rsrc_t cr = __builtin_amdgcn_make_buffer_rsrc(k.xcopy, 0, XCOPY ? (int)(npix_in * k.xc_ps * ESZ) : 0, 0x00020000);
+  const unsigned xps = (unsigned)k.x_ps * ESZ, cps = (unsigned)k.xc_ps * ESZ;
   for (long p = ix.p; p < npix; p += ix.pstep) {
     // (pixel counts are < 2^31: the host checks tensor sizes; 32-bit division is a third of the 64-bit sequence)
     const unsigned pu = (unsigned)p, ru = pu / (unsigned)k.OW;
     const int ox = (int)(pu - ru * (unsigned)k.OW);
     const int n = (int)(ru / (unsigned)k.OH);
     const int oy = (int)(ru - (unsigned)n * (unsigned)k.OH);
-    const long r = (long)ru;
-    (void)r;
+    ubr_u4 raw[9];
+    bool ok[9];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int iy = oy * S - 1 + ky, jx = ox * S - 1 + kx;
+        const bool in = (unsigned)iy < (unsigned)k.H && (unsigned)jx < (unsigned)k.W;
+        const unsigned ip = ((unsigned)n * (unsigned)k.H + (unsigned)iy) * (unsigned)k.W + (unsigned)jx;
+        ok[ky * 3 + kx] = in;
+        raw[ky * 3 + kx] = __builtin_amdgcn_raw_buffer_load_b128(xr, in ? (int)(ip * xps + (unsigned)ix.c * 16u) : kUnitOOR, 0, 0);
+      }
     float m[CPU];
     int am[CPU];
 #pragma unroll
     for (int e = 0; e < CPU; ++e) { m[e] = -FLT_MAX; am[e] = -1; }
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int iy = oy * k.stride - 1 + ky;
-      if ((unsigned)iy >= (unsigned)k.H) continue;
+    for (int t = 0; t < 9; ++t) {
+      float v[CPU];
+      unpack4<T>(raw[t], v);
+      if constexpr (XF) ubr_bnrelu<CPU>(v, sb, sc, sh, lo);
+      if constexpr (AMAX) {
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int jx = ox * k.stride - 1 + kx;
-        if ((unsigned)jx >= (unsigned)k.W) continue;
-        const long ip = ((long)n * k.H + iy) * k.W + jx;
-        float v[CPU];
-        ldunit<T>(k.x, ip, k.x_ps, ix.c, v);
-        if (xf) {
-          ubr_bnrelu<CPU>(v, sb, sc, sh, lo);
+        for (int e = 0; e < CPU; ++e)
+          if (ok[t] && (am[e] < 0 || v[e] > m[e])) { m[e] = v[e]; am[e] = t; }   // strict >: first maximum wins (ATen)
+      } else {
+#pragma unroll
+        for (int e = 0; e < CPU; ++e) m[e] = ok[t] ? fmaxf(m[e], v[e]) : m[e];
+      }
+      // each stride-2 window owns the 2x2 input pixels (2oy..2oy+1, 2ox..2ox+1) = taps ky,kx in {1,2}: always inside the image
+      if constexpr (XCOPY) {
+        if (t / 3 >= 1 && t % 3 >= 1) {
+          const unsigned ip = ((unsigned)n * (unsigned)k.H + (unsigned)(oy * S - 1 + t / 3)) * (unsigned)k.W + (unsigned)(ox * S - 1 + t % 3);
+          const uint4 pk = ET<T>::pack(v);
+          __builtin_amdgcn_raw_buffer_store_b128(ubr_u4{pk.x, pk.y, pk.z, pk.w}, cr, (int)(ip * cps + (unsigned)ix.c * 16u), 0, 0);
         }
-        if (k.amax != nullptr) {
-#pragma unroll
-          for (int e = 0; e < CPU; ++e)
-            if (am[e] < 0 || v[e] > m[e]) { m[e] = v[e]; am[e] = ky * 3 + kx; }   // strict >: first maximum wins (ATen)
-        } else {
-#pragma unroll
-          for (int e = 0; e < CPU; ++e) m[e] = fmaxf(m[e], v[e]);
-        }
-        // each stride-2 window owns the 2x2 input pixels (2oy..2oy+1, 2ox..2ox+1) = taps ky,kx in {1,2}
-        if (k.xcopy != nullptr && ky >= 1 && kx >= 1) stunit<T>(k.xcopy, ip, k.xc_ps, ix.c, v);
       }
     }
-    stunit<T>(k.pooled, p, k.p_ps, ix.c, m);
-    if (k.amax != nullptr) {
+    {
+      const uint4 pk = ET<T>::pack(m);
+      __builtin_amdgcn_raw_buffer_store_b128(ubr_u4{pk.x, pk.y, pk.z, pk.w}, pr, (int)(pu * (unsigned)k.p_ps * ESZ + (unsigned)ix.c * 16u), 0, 0);
+    }
+    if constexpr (AMAX) {
       uint8_t* a = k.amax + p * k.C + (long)ix.c * CPU;
       if constexpr (CPU == 8) {
         *reinterpret_cast<uint2*>(a) = make_uint2((unsigned)am[0] | ((unsigned)am[1] << 8) | ((unsigned)am[2] << 16) | ((unsigned)am[3] << 24),
@@ -1173,8 +1189,10 @@ static int pool_common(bool bwd, int dtype, int N, int H, int W, int C, int stri
       UBR_TRY(check_nhwc(who, dtype, npix_in, C, xcopy, xc_ps));
     }
     k.pooled = pooled; k.p_ps = p_ps; k.xcopy = xcopy; k.xc_ps = xc_ps;
-    const int blocks = pick_blocks(npix_out, k.CU);
-    UBR_DT_SWITCH(dtype, ubr_launch(maxpool_fwd_kernel<TT>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, k));
+    const int blocks = pick_blocks(npix_out, k.CU, 4096);
+    const bool am = amax != nullptr, xc = xcopy != nullptr;
+    if (stride == 2) { UBR_DT_SWITCH(dtype, UBR_BOOL3(hx, am, xc, ubr_launch((maxpool_fwd_kernel<TT, 2, B0, B1, B2>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, k))); }
+    else { UBR_DT_SWITCH(dtype, UBR_BOOL2(hx, am, ubr_launch((maxpool_fwd_kernel<TT, 1, B0, B1, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, k))); }
   } else {
     UBR_TRY(check_nhwc(who, dtype, npix_out, C, gp, gp_ps));
     if (ge) UBR_TRY(check_nhwc(who, dtype, npix_in, C, ge, ge_ps));

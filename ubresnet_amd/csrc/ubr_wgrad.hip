@@ -69,8 +69,16 @@ __device__ __forceinline__ uint4 sc_frag32(const char* p0, int pstride) {
 #define UBR_WGRAD_TALL 1
 #endif
 __host__ __device__ constexpr bool wgrad_tall(bool nsplit, int tpg, int ma) { return UBR_WGRAD_TALL && nsplit && tpg == 9 && ma == 2; }
+// K-split (thin-layer) kernels with at most two channel fragments: pixel tiles of UBR_WGRAD_KTH rows.  These layers are
+// HBM-bound, one workgroup per CU, and what they keep in flight is two pixel tiles; -DUBR_WGRAD_KTH=16 doubles it with 16-row
+// tiles.  Measured in the train step, same box: 11.80 vs 11.74 ms (slower: the longer-lived, larger workgroups cost the compute
+// stream more than the weight-gradient stream gains).  Default 8.
+#ifndef UBR_WGRAD_KTH
+#define UBR_WGRAD_KTH 8
+#endif
+__host__ __device__ constexpr int wgrad_kth(bool nsplit, int tpg, int ma, int nb) { return (!nsplit && tpg != 25 && ma * nb <= 2) ? UBR_WGRAD_KTH : 8; }
 __host__ __device__ constexpr int wgrad_xslots(bool nsplit, int tpg, int nb, int cpu, bool bigx, int ma = 0) {
-  return (bigx ? 12 : (wgrad_tall(nsplit, tpg, ma) ? 11 : (nsplit ? 7 : (tpg == 25 ? 5 : (nb == 1 ? 3 : 6))))) * (8 / cpu);
+  return (bigx ? 12 : (wgrad_tall(nsplit, tpg, ma) ? 11 : (nsplit ? 7 : (tpg == 25 ? 5 : (wgrad_kth(nsplit, tpg, ma, nb) == 16 ? (nb == 1 ? 5 : 10) : (nb == 1 ? 3 : 6)))))) * (8 / cpu);
 }
 
 template <typename T, int MA, int NB, int TPG, bool NSPLIT, bool BIGX>
@@ -107,7 +115,7 @@ __global__ __launch_bounds__(256, (TPG == 25 ? 2 : 1)) void wgrad_kernel(const W
   // of its channels sit in registers.  The tile loop is software-pipelined: the global loads of tile i+1 are
   // issued into registers (gv/xv) right before the MFMA phase of tile i and written to LDS after it. ----
   constexpr bool TALL = wgrad_tall(NSPLIT, TPG, MA);
-  constexpr int GS = ((NSPLIT && !TALL) ? 4 : 8) * 32 * UG / 256;       // G slots per thread (TH <= 4 / 8)
+  constexpr int GS = ((NSPLIT && !TALL) ? 4 : wgrad_kth(NSPLIT, TPG, MA, NB)) * 32 * UG / 256;       // G slots per thread (TH <= 4 / 8 / 16)
   constexpr int XS = wgrad_xslots(NSPLIT, TPG, NB, CPU, BIGX, MA);     // X slots per thread (host shrinks the tile until the halo fits)
   float xsub[CPU], xsc[CPU], xsh[CPU], xlo[CPU];
   if (has_xf) {
@@ -423,6 +431,7 @@ static int wgrad_plan(const ubr_wgrad_desc* d, WPlan* p) {
   if (TPG == 9 && MA == 2 && NB == 2) NB = 1;   // the 32 x 32 x 9-tap tile needs 320 VGPRs (one wave per SIMD); 32 x 16 fits two: 89 -> 64 us
   p->nsplit_mode = 0;
   p->TH = d->S == 1 ? 8 : 4;   // rows beyond GH are zero-filled, so small grids stay correct
+  if (wgrad_kth(false, TPG, MA, NB) == 16 && d->S == 1 && d->GH >= 16) p->TH = 16;
   if (TPG <= 9 && d->Cout % 64 == 0 && d->Cin % 64 == 0) {   // wide layers: 64 x 64 channel tile, waves split cin
     static const int ma9 = [] { const char* e = getenv("UBR_WGRAD_MA9"); return e ? atoi(e) : 2; }();
     MA = (TPG == 9) ? ma9 : 4; NB = 4; p->nsplit_mode = 1;   // 9 taps: 32 x 64 tile keeps the kernel under 256 VGPRs (2 waves/SIMD)
@@ -531,19 +540,13 @@ struct RedK {
   long sm, sk, slab_stride;
   int tapidx[UBR_MAX_TAPS];
 };
-constexpr int kRedGroup = 32;
-// stage 1: slabs [g*32, g*32+32) are summed (fixed order) into slab g*32, in place
-__global__ __launch_bounds__(256) void wgrad_reduce_stage1(float* slabs, long per, int nsplit) {
-  const int g = blockIdx.y;
-  const int s0 = g * kRedGroup, s1 = min(s0 + kRedGroup, nsplit);
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per; i += (long)gridDim.x * 256) {
-    float s = 0.f;
-#pragma unroll 8
-    for (int sp = s0; sp < s1; ++sp) s += slabs[(long)sp * per + i];
-    slabs[(long)s0 * per + i] = s;
-  }
-}
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedK k) {
+// One launch per weight gradient, whatever the number of slabs: a block owns 64 consecutive elements; its four waves each sum
+// a contiguous quarter of the slabs (eight loads in flight, added in slab order) and the four partials meet in LDS in a fixed
+// order -- bitwise reproducible, and no thread's serial chain is longer than nsplit / 4 loads.  (The first form took two launches
+// when there were more than 32 slabs: 35 extra launches per step on the weight-gradient stream.)
+constexpr int kRedMaxSplit = 1024;
+// few slabs (the wide layers: 2-8 slabs of up to 9.4 MB): one thread per element, every slab load in flight at once
+__global__ __launch_bounds__(256) void wgrad_reduce_flat_kernel(const RedK k) {
   const long per = (long)k.ntaps * k.Cout_pad * k.Cin;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per; i += (long)gridDim.x * 256) {
     const int ci = (int)(i % k.Cin);
@@ -556,6 +559,42 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedK k) {
     for (int sp = 0; sp < k.nsplit; ++sp) s += k.slabs[(long)sp * k.slab_stride + i];
     float* d = k.dst + (long)co * k.sm + (long)ci * k.sk + k.tapidx[t];
     *d = k.accumulate ? (*d + s) : s;
+  }
+}
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedK k) {
+  __shared__ float part[4][64];
+  const long per = (long)k.ntaps * k.Cout_pad * k.Cin;
+  const int e = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const int q = (k.nsplit + 3) / 4;
+  const int s0 = sg * q, s1 = min(s0 + q, k.nsplit);
+  for (long base = (long)blockIdx.x * 64; base < per; base += (long)gridDim.x * 64) {
+    const long i = base + e;
+    float s = 0.f;
+    if (i < per) {
+      int sp = s0;
+      for (; sp + 8 <= s1; sp += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = k.slabs[(long)(sp + u) * k.slab_stride + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
+      for (; sp < s1; ++sp) s += k.slabs[(long)sp * k.slab_stride + i];
+    }
+    part[sg][e] = s;
+    __syncthreads();
+    if (sg == 0 && i < per) {
+      const int ci = (int)(i % k.Cin);
+      long r = i / k.Cin;
+      const int co = (int)(r % k.Cout_pad);
+      const int t = (int)(r / k.Cout_pad);
+      if (co < k.Cout_valid && ci < k.Cin_valid) {
+        const float tot = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
+        float* d = k.dst + (long)co * k.sm + (long)ci * k.sk + k.tapidx[t];
+        *d = k.accumulate ? (*d + tot) : tot;
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -628,24 +667,19 @@ extern "C" int ubr_wgrad_reduce(float* slabs, int nsplit, int ntaps, int Cout_pa
                                 int Cout_valid, int Cin_valid, float* dst, int64_t sm, int64_t sk,
                                 const int32_t* tapidx_host, int accumulate, void* stream) {
   UBR_CHECK(slabs && dst && tapidx_host, "ubr_wgrad_reduce: null pointer");
-  UBR_CHECK(nsplit >= 1 && nsplit <= kRedGroup * kRedGroup && ntaps >= 1 && ntaps <= UBR_MAX_TAPS && Cout_pad > 0 && Cin > 0 &&
+  UBR_CHECK(nsplit >= 1 && nsplit <= kRedMaxSplit && ntaps >= 1 && ntaps <= UBR_MAX_TAPS && Cout_pad > 0 && Cin > 0 &&
             Cout_valid > 0 && Cout_valid <= Cout_pad && Cin_valid > 0 && Cin_valid <= Cin, "ubr_wgrad_reduce: bad extents");
   const long per = (long)ntaps * Cout_pad * Cin;
-  int blocks = (int)((per + 255) / 256);
+  const bool flat = nsplit <= 8;
+  int blocks = (int)((per + (flat ? 255 : 63)) / (flat ? 256 : 64));
   if (blocks > 8192) blocks = 8192;
   hipStream_t st = (hipStream_t)stream;
   RedK k{};
   k.slabs = slabs; k.dst = dst; k.nsplit = nsplit; k.ntaps = ntaps; k.Cout_pad = Cout_pad; k.Cin = Cin;
   k.Cout_valid = Cout_valid; k.Cin_valid = Cin_valid; k.accumulate = accumulate; k.sm = sm; k.sk = sk; k.slab_stride = per;
   for (int t = 0; t < ntaps; ++t) k.tapidx[t] = tapidx_host[t];
-  if (nsplit > kRedGroup) {
-    // two-level tree keeps every thread's serial chain <= 32 loads (a single pass over 1024 slabs is latency-bound)
-    const int groups = ubr_cdiv(nsplit, kRedGroup);
-    ubr_launch(wgrad_reduce_stage1, dim3(blocks, groups), dim3(256), 0, st, slabs, per, nsplit);
-    UBR_LAUNCH_CHECK("ubr_wgrad_reduce(stage1)");
-    k.nsplit = groups; k.slab_stride = per * kRedGroup;
-  }
-  ubr_launch(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, k);
+  if (flat) ubr_launch(wgrad_reduce_flat_kernel, dim3(blocks), dim3(256), 0, st, k);
+  else ubr_launch(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, k);
   UBR_LAUNCH_CHECK("ubr_wgrad_reduce");
   return UBR_OK;
 }

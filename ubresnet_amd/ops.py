@@ -350,7 +350,7 @@ def wgrad(x: torch.Tensor, g: torch.Tensor, taps, dst: torch.Tensor, sm: int, sk
         sig = "%s %s taps%d S%d" % ("x".join(map(str, x.shape)), "x".join(map(str, g.shape)), len(taps), S)
         nbytes = (x.numel() + g.numel()) * x.element_size()
         flops = 2.0 * g.shape[0] * g.shape[1] * g.shape[2] * g.shape[3] * Cin * len(taps)
-        red = ("wgrad_reduce", "wgrad_reduce_kernel (+stage1)", sig, nsplit.value * len(taps) * d.Cout * Cin * 4, 0.0)
+        red = ("wgrad_reduce", "wgrad_reduce_kernel", sig, nsplit.value * len(taps) * d.Cout * Cin * 4, 0.0)
         if sink is not None:
             sink.labels[lab0] = ("wgrad", kern, sig, nbytes, flops)
             sink.label_end(lab1, red)
