@@ -113,6 +113,9 @@ typedef struct {
   const uint8_t* addend_mask;
   ubr_tensor bnb_c;
   const float *bnb_mean, *bnb_scale, *bnb_shift, *bnb_invstd;
+  int32_t stats_slots;       /* stripes of `stats` to use: 0 = UBR_STAT_SLOTS; UBR_RED_SLOTS when the consumer sums them itself
+                              * (ubr_block_tail_fwd_fin).  bnb_c always uses UBR_RED_SLOTS. */
+  int32_t pad2_;
 } ubr_conv_desc;
 
 int ubr_conv(const ubr_conv_desc* d, void* stream);
@@ -262,6 +265,22 @@ int ubr_block_tail_bwd_apply(int dtype, int64_t npix, int C, const void* go, int
                              const void* cb, int64_t cb_ps, const float* scale_b, const float* mean_b, const float* invstd_b,
                              const float* k1_b, const float* k2_b,
                              void* g_c2, int64_t g_c2_ps, void* g_sc, int64_t g_sc_ps, void* stream);
+
+/* Forward with the train-mode BatchNorm finalize(s) fused: the convs that produced c2 (and cb) accumulated their statistics with
+ * UBR_RED_SLOTS stripes (ubr_conv_desc.stats_slots); every workgroup forms mean / scale from them, workgroup 0 writes the
+ * site's vectors (for the backward pass), the running statistics and the batch counter -- ubr_bn_finalize's arithmetic, without
+ * its launches on the dependent chain.  momentum < 0 = cumulative averaging (nn.BatchNorm2d(momentum=None)).  bn_b NULL =
+ * identity shortcut.  relu_mask may be NULL.  Needs 12*C (24*C) bytes of LDS. */
+typedef struct {
+  const double* stats;             /* [UBR_STAT_SLOTS][2*C] of which the first UBR_RED_SLOTS stripes are used */
+  const float *gamma, *beta;
+  float *running_mean, *running_var; int64_t* num_batches_tracked;     /* all NULL: not tracked */
+  float momentum, eps;
+  float *scale, *shift, *mean, *invstd;                                 /* outputs, C floats each */
+} ubr_bn_fwd_fin;
+int ubr_block_tail_fwd_fin(int dtype, int64_t npix, int C, const void* c2, int64_t c2_ps, const ubr_bn_fwd_fin* bn2,
+                           const void* sc, int64_t sc_ps, const ubr_bn_fwd_fin* bn_b, double count,
+                           void* out, int64_t out_ps, uint8_t* relu_mask, void* stream);
 
 /* The same three with the final ReLU's mask kept as bits: `relu_mask` holds one byte per pixel and 16-byte channel unit
  * ([npix][C / channels-per-unit], bit e = "stored output of channel e of the unit is > 0").  The forward writes it beside

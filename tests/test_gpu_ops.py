@@ -466,6 +466,50 @@ def test_block_tail(dt, bypass, C, N, H, W):
     torch.cuda.synchronize()
     assert torch.equal(g_c2m, g_c2) and torch.equal(g_scm, g_sc)
     assert torch.allclose(slotsum(red2m, 2 * C), slotsum(red2, 2 * C), rtol=1e-12, atol=1e-9)
+    # forward with the BatchNorm finalizes fused (ubr_block_tail_fwd_fin): from the striped conv statistics to the block output in
+    # one launch -- bitwise what ubr_bn_finalize + ubr_block_tail_fwd_masked give, vectors, running statistics and counters included
+    import torch.nn as nn
+    def site(src, gamma, beta):
+        bn = nn.BatchNorm2d(C).to(DEV)
+        with torch.no_grad():
+            bn.weight.copy_(gamma); bn.bias.copy_(beta); bn.running_mean.uniform_(-1, 1); bn.running_var.uniform_(0.5, 2)
+        st = statbuf(2 * C)
+        sv = nhwc(src, dt).double().reshape(-1, C)      # the statistics a producing conv would have accumulated, over 3 stripes
+        st[:2 * C] = torch.cat([sv.sum(0), (sv * sv).sum(0)]) * 0.5
+        st[2 * C:4 * C] = st[:2 * C] * 0.25
+        st[8 * C:10 * C] = st[:2 * C] * 0.75            # stripe 4
+        return bn, st
+    for mom in (0.1, None):
+        res = []
+        for fused in (False, True):
+            torch.manual_seed(5)
+            bn_2, st2 = site(c2, g2, b2)
+            bn_b, stb = site(sc_in, gb, bb)
+            bn_2.momentum = bn_b.momentum = mom
+            v2 = [torch.empty(C, device=DEV) for _ in range(4)]
+            vb = [torch.empty(C, device=DEV) for _ in range(4)]
+            o = torch.empty_like(outd)
+            mk = torch.zeros_like(mask)
+            if fused:
+                f2 = ops.bn_fwd_fin(st2, bn_2, *v2)
+                fb = ops.bn_fwd_fin(stb, bn_b, *vb) if bypass else None
+                ops.block_tail_fwd_fin(c2d, f2, scd, fb, cnt, o, relu_mask=mk)
+            else:
+                for bn_, st_, v_ in ((bn_2, st2, v2),) + (((bn_b, stb, vb),) if bypass else ()):
+                    ops.bn_finalize(st_, cnt, bn_.weight, bn_.bias, bn_.running_mean, bn_.running_var, bn_.num_batches_tracked,
+                                    -1.0 if mom is None else mom, bn_.eps, *v_)
+                ops.block_tail_fwd(c2d, v2[2], v2[0], v2[1], scd, vb[2] if bypass else None, vb[0] if bypass else None, vb[1] if bypass else None, o, relu_mask=mk)
+            torch.cuda.synchronize()
+            res.append((o, mk, v2, vb, bn_2, bn_b))
+        (o0, m0, v20, vb0, bnA0, bnB0), (o1, m1, v21, vb1, bnA1, bnB1) = res
+        assert torch.equal(o0, o1) and torch.equal(m0, m1)
+        for a_, b_ in zip(v20, v21):
+            assert torch.equal(a_, b_)
+        assert torch.equal(bnA0.running_mean, bnA1.running_mean) and torch.equal(bnA0.running_var, bnA1.running_var) and int(bnA1.num_batches_tracked) == 1
+        if bypass:
+            for a_, b_ in zip(vb0, vb1):
+                assert torch.equal(a_, b_)
+            assert torch.equal(bnB0.running_mean, bnB1.running_mean) and torch.equal(bnB0.running_var, bnB1.running_var) and int(bnB1.num_batches_tracked) == 1
     # apply pass with both finalizes fused (no ubr_bn_bwd_finalize launch): bitwise the same gradients and dgamma / dbeta;
     # with and without the second gradient operand (separate kernel instantiations)
     for second in (go2d, None):

@@ -66,6 +66,17 @@ class ConvDesc(C.Structure):
         ("addend_mask", C.c_void_p),
         ("bnb_c", Tensor),
         ("bnb_mean", C.c_void_p), ("bnb_scale", C.c_void_p), ("bnb_shift", C.c_void_p), ("bnb_invstd", C.c_void_p),
+        ("stats_slots", C.c_int32), ("pad2_", C.c_int32),
+    ]
+
+
+class BnFwdFin(C.Structure):
+    """ubr_bn_fwd_fin"""
+    _fields_ = [
+        ("stats", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+        ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("num_batches_tracked", C.c_void_p),
+        ("momentum", C.c_float), ("eps", C.c_float),
+        ("scale", C.c_void_p), ("shift", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p),
     ]
 
 
@@ -93,7 +104,7 @@ SYMBOLS = [
     "ubr_bn_finalize", "ubr_bn_eval_affine", "ubr_bn_bwd_reduce", "ubr_bn_bwd_finalize", "ubr_bn_bwd_apply",
     "ubr_block_tail_fwd", "ubr_block_tail_bwd_reduce", "ubr_block_tail_bwd_apply",
     "ubr_block_tail_fwd_masked", "ubr_block_tail_bwd_reduce_masked", "ubr_block_tail_bwd_apply_masked",
-    "ubr_bn_bwd_apply_fin", "ubr_block_tail_bwd_apply_fin",
+    "ubr_bn_bwd_apply_fin", "ubr_block_tail_bwd_apply_fin", "ubr_block_tail_fwd_fin",
     "ubr_maxpool_fwd", "ubr_maxpool_bwd",
     "ubr_logsoftmax_bwd", "ubr_pixelwise_nll_fwd", "ubr_pixelwise_nll_bwd", "ubr_confusion",
     "ubr_channel_sum", "ubr_cast_f64_to_f32", "ubr_zero", "ubr_adam_step", "ubr_sgd_step", "ubr_crop_tiles", "ubr_stitch_tiles", "ubr_last_error", "ubr_version",
@@ -134,6 +145,7 @@ def _declare(lib):
     lib.ubr_bn_bwd_apply_fin.argtypes = [i32, i64, i32, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i32, vp, f64, vp, vp, vp, i64, vp]
     lib.ubr_block_tail_bwd_apply_fin.argtypes = [i32, i64, i32, vp, i64, vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp,
                                                  vp, i64, vp, vp, vp, vp, vp, vp, f64, vp, i64, vp, i64, vp]
+    lib.ubr_block_tail_fwd_fin.argtypes = [i32, i64, i32, vp, i64, C.POINTER(BnFwdFin), vp, i64, C.POINTER(BnFwdFin), f64, vp, i64, vp, vp]
     lib.ubr_block_tail_fwd.argtypes = [i32, i64, i32, vp, i64, vp, vp, vp, vp, i64, vp, vp, vp, vp, i64, vp]
     lib.ubr_block_tail_fwd_masked.argtypes = [i32, i64, i32, vp, i64, vp, vp, vp, vp, i64, vp, vp, vp, vp, i64, vp, vp]
     lib.ubr_block_tail_bwd_reduce_masked.argtypes = [i32, i64, i32, vp, i64, vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp]

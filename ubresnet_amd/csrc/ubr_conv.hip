@@ -1437,7 +1437,7 @@ __global__ __launch_bounds__(512) void conv_pc_kernel(const ConvK k) {
       const float a = srow[lane], b = srow[TN + lane];
       const int ch = n0 + lane;
       if (ch < k.Cout) {
-        double* st = k.stats + (size_t)((blockIdx.x * 4 + wave) % UBR_STAT_SLOTS) * 2 * k.Cout;
+        double* st = k.stats + (size_t)((blockIdx.x * 4 + wave) % k.nslots) * 2 * k.Cout;
         atomicAdd(&st[ch], (double)a);
         atomicAdd(&st[k.Cout + ch], (double)b);
       }
@@ -2076,7 +2076,8 @@ extern "C" int ubr_conv(const ubr_conv_desc* d, void* stream) {
   k.ad_mask = d->addend_mask; k.ad_mask_cu = d->Cout / cpu;
   k.bc = (const char*)d->bnb_c.p; k.bc_sn = d->bnb_c.sn * esz; k.bc_sy = d->bnb_c.sy * esz; k.bc_sx = d->bnb_c.sx * esz;
   k.bmean = d->bnb_mean; k.bscale = d->bnb_scale; k.bshift = d->bnb_shift; k.binvstd = d->bnb_invstd;
-  k.nslots = d->bnb_c.p != nullptr ? UBR_RED_SLOTS : UBR_STAT_SLOTS;
+  UBR_CHECK(d->stats_slots == 0 || d->stats_slots == UBR_RED_SLOTS || d->stats_slots == UBR_STAT_SLOTS, "ubr_conv: stats_slots must be 0, %d or %d", UBR_RED_SLOTS, UBR_STAT_SLOTS);
+  k.nslots = (d->bnb_c.p != nullptr || d->stats_slots == UBR_RED_SLOTS) ? UBR_RED_SLOTS : UBR_STAT_SLOTS;
   k.H = d->H; k.W = d->W;
   k.CU = d->Cin / cpu; k.UPB = best.UPB; k.lgUPB = ubr_ilog2(best.UPB); k.nblk = k.CU / best.UPB;
   k.Cout = d->Cout; k.Cout_pad = d->Cout_pad;

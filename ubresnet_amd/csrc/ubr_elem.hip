@@ -198,21 +198,82 @@ template <typename T> __device__ __forceinline__ void unpack4(const ubr_u4& v, f
 // ------------------------------------------------------------------------------------------
 // BasicBlock tail forward
 // ------------------------------------------------------------------------------------------
+// train-mode BatchNorm finalize of one site, fused into its consumer (ubr_block_tail_fwd_fin): the producing conv's striped
+// fp64 sums in, the site's vectors out (written by workgroup 0; every workgroup computes its own copy into LDS)
+struct BnFwdFin {
+  const double* stats; const float *gamma, *beta;
+  float *rmean, *rvar; long long* nbt;
+  float momentum, eps;
+  float *scale, *shift, *mean, *invstd;
+};
 struct TailF {
-  long npix; int CU;
+  long npix; int CU, C;
   const void *c2, *sc; void* out; long c2_ps, sc_ps, out_ps;
   const float *m2, *s2, *t2, *mb, *sb, *tb;
   uint8_t* relu_mask;
+  BnFwdFin f2, fb;               // fused finalize (f2.stats != nullptr): m2/s2/t2 (mb/sb/tb) are not read
+  double count; int nslots;
 };
+// -> kk[0..C) mean, kk[C..2C) scale, kk[2C..3C) shift.  Same arithmetic as bn_finalize_kernel.
+__device__ __forceinline__ void fwd_fin_site(const BnFwdFin& f, int nslots, int C, double count, float* kk, float mom_cum) {
+  for (int c = threadIdx.x; c < C; c += 256) {
+    double s1 = 0.0, s2 = 0.0;
+    if (nslots == UBR_RED_SLOTS) {
+      double a[UBR_RED_SLOTS], b[UBR_RED_SLOTS];
+#pragma unroll
+      for (int sl = 0; sl < UBR_RED_SLOTS; ++sl) { a[sl] = f.stats[(size_t)sl * 2 * C + c]; b[sl] = f.stats[(size_t)sl * 2 * C + C + c]; }
+#pragma unroll
+      for (int sl = 0; sl < UBR_RED_SLOTS; ++sl) { s1 += a[sl]; s2 += b[sl]; }
+    } else {
+      for (int sl = 0; sl < nslots; ++sl) { s1 += f.stats[(size_t)sl * 2 * C + c]; s2 += f.stats[(size_t)sl * 2 * C + C + c]; }
+    }
+    const double m = s1 / count;
+    double var = s2 / count - m * m;
+    if (var < 0.0) var = 0.0;
+    const double is = 1.0 / sqrt(var + (double)f.eps);
+    const float sc = (float)((double)f.gamma[c] * is);
+    kk[c] = (float)m; kk[C + c] = sc; kk[2 * C + c] = f.beta[c];
+    if (blockIdx.x == 0) {
+      f.scale[c] = sc; f.shift[c] = f.beta[c]; f.mean[c] = (float)m; f.invstd[c] = (float)is;
+      if (f.rmean != nullptr) {
+        const double momentum = f.momentum < 0.f ? (double)mom_cum : (double)f.momentum;
+        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        f.rmean[c] = (float)((1.0 - momentum) * (double)f.rmean[c] + momentum * m);
+        f.rvar[c] = (float)((1.0 - momentum) * (double)f.rvar[c] + momentum * unb);
+      }
+    }
+  }
+}
 template <typename T, bool BYP, bool MASK>
 __global__ __launch_bounds__(256) void tail_fwd_kernel(const TailF k) {
   constexpr int CPU = ET<T>::CPU;
   constexpr int H2 = CPU / 2;
   constexpr int UNR = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   UnitIdx<T> ix(k.CU);
   ubr_f2 a2[H2], b2[H2], m2[H2], ab[H2], bb[H2], mb[H2];
-  ldconst2<CPU>(k.s2, ix.c, a2); ldconst2<CPU>(k.t2, ix.c, b2); ldconst2<CPU>(k.m2, ix.c, m2);
-  if (BYP) { ldconst2<CPU>(k.sb, ix.c, ab); ldconst2<CPU>(k.tb, ix.c, bb); ldconst2<CPU>(k.mb, ix.c, mb); }
+  if (k.f2.stats != nullptr) {
+    float* kk = reinterpret_cast<float*>(smem);
+    // (momentum = None: cumulative average; only workgroup 0 touches the counters)
+    float cum2 = 0.f, cumb = 0.f;
+    if (blockIdx.x == 0) {
+      if (k.f2.nbt != nullptr) cum2 = (float)(1.0 / (double)(*k.f2.nbt + 1));
+      if (BYP && k.fb.nbt != nullptr) cumb = (float)(1.0 / (double)(*k.fb.nbt + 1));
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        if (k.f2.nbt != nullptr) *k.f2.nbt += 1;
+        if (BYP && k.fb.nbt != nullptr) *k.fb.nbt += 1;
+      }
+    }
+    fwd_fin_site(k.f2, k.nslots, k.C, k.count, kk, cum2);
+    if (BYP) fwd_fin_site(k.fb, k.nslots, k.C, k.count, kk + 3 * k.C, cumb);
+    __syncthreads();
+    ldconst2<CPU>(kk, ix.c, m2); ldconst2<CPU>(kk + k.C, ix.c, a2); ldconst2<CPU>(kk + 2 * k.C, ix.c, b2);
+    if (BYP) { ldconst2<CPU>(kk + 3 * k.C, ix.c, mb); ldconst2<CPU>(kk + 4 * k.C, ix.c, ab); ldconst2<CPU>(kk + 5 * k.C, ix.c, bb); }
+  } else {
+    ldconst2<CPU>(k.s2, ix.c, a2); ldconst2<CPU>(k.t2, ix.c, b2); ldconst2<CPU>(k.m2, ix.c, m2);
+    if (BYP) { ldconst2<CPU>(k.sb, ix.c, ab); ldconst2<CPU>(k.tb, ix.c, bb); ldconst2<CPU>(k.mb, ix.c, mb); }
+  }
   UnitTrip<T, UNR> C2(k.c2, k.npix, k.c2_ps, ix), SC(k.sc, k.npix, k.sc_ps, ix), OUT(k.out, k.npix, k.out_ps, ix);
   MaskTrip<T, UNR> MK(k.relu_mask, k.npix, k.CU, ix);
   const float zero = 0.f;
@@ -904,18 +965,41 @@ static int check_nhwc(const char* who, int dtype, int64_t npix, int C, const voi
 
 static int tail_fwd_common(int dtype, int64_t npix, int C, const void* c2, int64_t c2_ps, const float* mean2, const float* scale2,
                            const float* shift2, const void* sc, int64_t sc_ps, const float* mean_b, const float* scale_b,
-                           const float* shift_b, void* out, int64_t out_ps, uint8_t* relu_mask, void* stream) {
+                           const float* shift_b, void* out, int64_t out_ps, uint8_t* relu_mask, void* stream,
+                           const ubr_bn_fwd_fin* fin2 = nullptr, const ubr_bn_fwd_fin* finb = nullptr, double count = 0.0) {
   UBR_TRY(check_nhwc("ubr_block_tail_fwd(c2)", dtype, npix, C, c2, c2_ps));
   UBR_TRY(check_nhwc("ubr_block_tail_fwd(sc)", dtype, npix, C, sc, sc_ps));
   UBR_TRY(check_nhwc("ubr_block_tail_fwd(out)", dtype, npix, C, out, out_ps));
-  UBR_CHECK(mean2 && scale2 && shift2 && ((scale_b == nullptr) == (shift_b == nullptr)) && ((scale_b == nullptr) == (mean_b == nullptr)), "ubr_block_tail_fwd: bad affine pointers");
   TailF k{};
-  k.npix = npix; k.CU = C / ubr_cpu(dtype);
+  k.npix = npix; k.CU = C / ubr_cpu(dtype); k.C = C;
   k.c2 = c2; k.sc = sc; k.out = out; k.c2_ps = c2_ps; k.sc_ps = sc_ps; k.out_ps = out_ps;
-  k.m2 = mean2; k.s2 = scale2; k.t2 = shift2; k.mb = mean_b; k.sb = scale_b; k.tb = shift_b; k.relu_mask = relu_mask;
-  const int blocks = pick_blocks(npix, k.CU, 2048, 4);
-  const bool byp = scale_b != nullptr, msk = relu_mask != nullptr;
-  UBR_DT_SWITCH(dtype, UBR_BOOL2(byp, msk, ubr_launch((tail_fwd_kernel<TT, B0, B1>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, k)));
+  k.relu_mask = relu_mask;
+  bool byp;
+  size_t lds = 0;
+  if (fin2 != nullptr) {
+    auto conv = [](const ubr_bn_fwd_fin* f, BnFwdFin* o) {
+      o->stats = f->stats; o->gamma = f->gamma; o->beta = f->beta; o->rmean = f->running_mean; o->rvar = f->running_var;
+      o->nbt = (long long*)f->num_batches_tracked; o->momentum = f->momentum; o->eps = f->eps;
+      o->scale = f->scale; o->shift = f->shift; o->mean = f->mean; o->invstd = f->invstd;
+    };
+    auto ok = [](const ubr_bn_fwd_fin* f) {
+      return f->stats && f->gamma && f->beta && f->scale && f->shift && f->mean && f->invstd && ((f->running_mean == nullptr) == (f->running_var == nullptr)) &&
+             (f->momentum >= 0.f || f->num_batches_tracked != nullptr);
+    };
+    UBR_CHECK(ok(fin2) && (finb == nullptr || ok(finb)) && count >= 1.0 && (size_t)24 * C <= 65536, "ubr_block_tail_fwd_fin: bad arguments");
+    conv(fin2, &k.f2);
+    if (finb != nullptr) conv(finb, &k.fb);
+    k.count = count; k.nslots = UBR_RED_SLOTS;
+    byp = finb != nullptr;
+    lds = (size_t)(byp ? 24 : 12) * C;
+  } else {
+    UBR_CHECK(mean2 && scale2 && shift2 && ((scale_b == nullptr) == (shift_b == nullptr)) && ((scale_b == nullptr) == (mean_b == nullptr)), "ubr_block_tail_fwd: bad affine pointers");
+    k.m2 = mean2; k.s2 = scale2; k.t2 = shift2; k.mb = mean_b; k.sb = scale_b; k.tb = shift_b;
+    byp = scale_b != nullptr;
+  }
+  const int blocks = pick_blocks(npix, k.CU, fin2 != nullptr ? 1024 : 2048, 4);
+  const bool msk = relu_mask != nullptr;
+  UBR_DT_SWITCH(dtype, UBR_BOOL2(byp, msk, ubr_launch((tail_fwd_kernel<TT, B0, B1>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, k)));
   UBR_LAUNCH_CHECK("ubr_block_tail_fwd");
   return UBR_OK;
 }
@@ -932,6 +1016,13 @@ extern "C" int ubr_block_tail_fwd_masked(int dtype, int64_t npix, int C, const v
 }
 
 struct TailFin { const double *red2, *redb; double count; float *dgamma2, *dbeta2, *dgamma_b, *dbeta_b; };
+
+extern "C" int ubr_block_tail_fwd_fin(int dtype, int64_t npix, int C, const void* c2, int64_t c2_ps, const ubr_bn_fwd_fin* bn2,
+                                      const void* sc, int64_t sc_ps, const ubr_bn_fwd_fin* bn_b, double count,
+                                      void* out, int64_t out_ps, uint8_t* relu_mask, void* stream) {
+  UBR_CHECK(bn2 != nullptr, "ubr_block_tail_fwd_fin: null bn2");
+  return tail_fwd_common(dtype, npix, C, c2, c2_ps, nullptr, nullptr, nullptr, sc, sc_ps, nullptr, nullptr, nullptr, out, out_ps, relu_mask, stream, bn2, bn_b, count);
+}
 
 static int tail_bwd_common(bool apply, int dtype, int64_t npix, int C, const void* go, int64_t go_ps, const void* go2, int64_t go2_ps,
                            const void* out, int64_t out_ps, const void* c2, int64_t c2_ps,

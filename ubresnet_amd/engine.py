@@ -34,9 +34,10 @@ import os as _os
 # UBR_INFER_FOLD=0: eval forward on the training schedule (BatchNorm applied on load, separate block tails) -- for A/B tests
 _INFER_FOLD = _os.environ.get("UBR_INFER_FOLD", "1") != "0"
 _RELU_MASK = _os.environ.get("UBR_RELU_MASK", "1") != "0"      # block tails keep their final ReLU's mask as bits for the backward
-# BatchNorm-backward finalize fused into the apply pass (every workgroup re-sums the reduce pass's stripes) up to this many
-# channels; wider layers keep the separate ubr_bn_bwd_finalize launch (the re-summation grows with C, the launch does not)
-_FIN_MAX_C = int(_os.environ.get("UBR_FIN_MAX_C", "64"))
+# BatchNorm-backward finalize fused into the apply pass (every workgroup re-sums the reduce pass's 8 stripes) up to this many
+# channels.  Measured: isolated, the fused apply costs +0.3 ... +2 us over the plain one at every width (512 channels: 8.7 vs
+# 8.4 us) against ~5 us of finalize launch; in the train step 64 vs all widths is within noise -- all widths, for the launches.
+_FIN_MAX_C = int(_os.environ.get("UBR_FIN_MAX_C", "1024"))
 # BatchNorm-backward reduce passes folded into the epilogue of the data-gradient conv that produces their gradient operand
 # (ubr_conv_desc.bnb_c), and identity-block skip gradients re-formed from the ReLU bit mask in the consuming conv's epilogue
 # (ubr_conv_desc.addend_mask) instead of being written by the tail's backward
@@ -48,6 +49,8 @@ _WG_MAIN_EVERY = int(_os.environ.get("UBR_WGRAD_MAIN_EVERY", "0"))
 # UBR_WGRAD_ORDER=after: a block's weight gradients are issued right AFTER the data-gradient conv that shares their gradient
 # operand (single-stream schedule: the operand is then still in L2 / MALL); default: before it (side stream: earliest start)
 _WG_AFTER = _os.environ.get("UBR_WGRAD_ORDER", "before") == "after"
+# train-mode forward: the finalize launches of a block's bn2 / bnpass are fused into the block tail kernel
+_TAIL_FIN = _os.environ.get("UBR_TAIL_FIN", "1") != "0"
 
 
 def _phase(t, ry, rx):
@@ -306,19 +309,27 @@ class Engine:
         ops.conv(x, self.packed(blk.conv1.weight, dt, "fwd"), c1, T3, Cout, S=S, xf=xf_in, stats=bn1.stats)
         self._finish_bn(bn1, cnt, training)
         c2 = self._new((N, OH, OW, Cout), dtype=dt, device=dev)
-        ops.conv(c1, self.packed(blk.conv2.weight, dt, "fwd"), c2, T3, Cout, xf=self.relu_affine(bn1), stats=bn2.stats)
-        self._finish_bn(bn2, cnt, training)
+        fuse = _TAIL_FIN and training and 24 * Cout <= 65536
+        slots = L.RED_SLOTS if fuse else 0
+        ops.conv(c1, self.packed(blk.conv2.weight, dt, "fwd"), c2, T3, Cout, xf=self.relu_affine(bn1), stats=bn2.stats, stats_slots=slots)
+        if not fuse:
+            self._finish_bn(bn2, cnt, training)
         cb = None
         if blk.bypass is not None:
             bnb = self.bn(blk.bnpass)
             cb = self._new((N, OH, OW, Cout), dtype=dt, device=dev)
-            ops.conv(x, self.packed(blk.bypass.weight, dt, "fwd"), cb, T1, Cout, S=S, xf=xf_in, stats=bnb.stats)
-            self._finish_bn(bnb, cnt, training)
+            ops.conv(x, self.packed(blk.bypass.weight, dt, "fwd"), cb, T1, Cout, S=S, xf=xf_in, stats=bnb.stats, stats_slots=slots)
+            if not fuse:
+                self._finish_bn(bnb, cnt, training)
         # the final ReLU's mask as one byte per 16-byte channel unit: the backward's two passes read it instead of `out`
         mask = None
         if self._save and _RELU_MASK:
             mask = self._new((cnt * (Cout // L.chans_per_unit(dt)),), dtype=torch.uint8, device=dev)
-        if blk.bypass is not None:
+        if fuse:
+            f2 = ops.bn_fwd_fin(bn2.stats, blk.bn2, bn2.scale, bn2.shift, bn2.mean, bn2.invstd)
+            fb = ops.bn_fwd_fin(bnb.stats, blk.bnpass, bnb.scale, bnb.shift, bnb.mean, bnb.invstd) if blk.bypass is not None else None
+            ops.block_tail_fwd_fin(c2, f2, cb if blk.bypass is not None else x, fb, cnt, out, relu_mask=mask)
+        elif blk.bypass is not None:
             ops.block_tail_fwd(c2, bn2.mean, bn2.scale, bn2.shift, cb, bnb.mean, bnb.scale, bnb.shift, out, relu_mask=mask)
         else:
             ops.block_tail_fwd(c2, bn2.mean, bn2.scale, bn2.shift, x, None, None, None, out, relu_mask=mask)

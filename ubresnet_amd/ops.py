@@ -205,7 +205,7 @@ def _tap_arrays(taps):
 def conv(x: torch.Tensor, wp: torch.Tensor, y: torch.Tensor, taps, Cout: int, S: int = 1, iy0: int = 0, ix0: int = 0,
          xf: Optional[Affine] = None, bias: Optional[torch.Tensor] = None, addend: Optional[torch.Tensor] = None,
          stats: Optional[torch.Tensor] = None, logsoftmax: bool = False, tile_hint: int = 0, in_hw=None, act: int = 0,
-         addend_mask: Optional[torch.Tensor] = None, bnb=None):
+         addend_mask: Optional[torch.Tensor] = None, bnb=None, stats_slots: int = 0):
     """One ubr_conv launch.  x: NHWC input view; y: NHWC output-grid view (or, with logsoftmax, the
     contiguous fp32 NCHW result); taps: [(dy,dx,packed tap index)].
     addend_mask: the ReLU bit mask of a block tail gating `addend` (out = conv + addend * bit);
@@ -255,6 +255,7 @@ def conv(x: torch.Tensor, wp: torch.Tensor, y: torch.Tensor, taps, Cout: int, S:
         assert xf.scale.numel() >= Cin
     d.tile_hint = tile_hint
     d.act = act
+    d.stats_slots = stats_slots
     if addend_mask is not None:
         assert addend is not None and addend_mask.dtype == torch.uint8 and addend_mask.is_contiguous()
         assert addend_mask.numel() >= y.shape[0] * y.shape[1] * y.shape[2] * (Cout // L.chans_per_unit(x.dtype))
@@ -459,6 +460,28 @@ def block_tail_fwd(c2, mean2, scale2, shift2, sc, mean_b, scale_b, shift_b, out,
         L.check(L.lib().ubr_block_tail_fwd(*a, L.stream_ptr()), "block_tail_fwd")
     else:
         L.check(L.lib().ubr_block_tail_fwd_masked(*a, relu_mask.data_ptr(), L.stream_ptr()), "block_tail_fwd_masked")
+
+
+def bn_fwd_fin(stats, bn, scale, shift, mean, invstd) -> "L.BnFwdFin":
+    """descriptor of a train-mode BatchNorm site whose finalize is fused into its consumer (ubr_bn_fwd_fin)"""
+    f = L.BnFwdFin()
+    track = bn.track_running_stats and bn.running_mean is not None
+    f.stats, f.gamma, f.beta = stats.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr()
+    f.running_mean = bn.running_mean.data_ptr() if track else None
+    f.running_var = bn.running_var.data_ptr() if track else None
+    f.num_batches_tracked = bn.num_batches_tracked.data_ptr() if track else None
+    f.momentum = -1.0 if bn.momentum is None else float(bn.momentum)
+    f.eps = float(bn.eps)
+    f.scale, f.shift, f.mean, f.invstd = scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr()
+    return f
+
+
+@_timed("block_tail_fwd")
+def block_tail_fwd_fin(c2, fin2, sc, fin_b, count, out, relu_mask=None):
+    """block tail forward with the BatchNorm finalize(s) of bn2 (and bnpass) fused: fin2 / fin_b from bn_fwd_fin()"""
+    L.check(L.lib().ubr_block_tail_fwd_fin(L.dtype_id(c2.dtype), _npix(c2), c2.shape[3], c2.data_ptr(), _ps(c2), C.byref(fin2),
+                                           sc.data_ptr(), _ps(sc), C.byref(fin_b) if fin_b is not None else None, float(count),
+                                           out.data_ptr(), _ps(out), L.ptr(relu_mask), L.stream_ptr()), "block_tail_fwd_fin")
 
 
 @_timed("block_tail_bwd_reduce")
