@@ -113,6 +113,15 @@ typedef struct {
   const uint8_t* addend_mask;
   ubr_tensor bnb_c;
   const float *bnb_mean, *bnb_scale, *bnb_shift, *bnb_invstd;
+  /* Several output phases in ONE launch (nphase 2..4; 0 or 1 = the single launch described above): the phases of a stride-2
+   * transposed conv, or of the data gradient of a stride-2 conv, share x and w but have their own taps and their own strided view of
+   * the output (and of the addend).  dy/dx/wt hold the phases' taps back to back: phase p uses taps [phase_tap0[p], +phase_ntaps[p]);
+   * its output view is `y` moved by phase_yoff[p] elements (same strides, same OH x OW), its addend `addend` moved by
+   * phase_aoff[p].  Same arithmetic per output element as one launch per phase; no statistics / training epilogues. */
+  int32_t nphase;
+  int32_t phase_tap0[4], phase_ntaps[4];
+  int32_t pad3_;
+  int64_t phase_yoff[4], phase_aoff[4];
   int32_t stats_slots;       /* stripes of `stats` to use: 0 = UBR_STAT_SLOTS; UBR_RED_SLOTS when the consumer sums them itself
                               * (ubr_block_tail_fwd_fin).  bnb_c always uses UBR_RED_SLOTS. */
   int32_t pad2_;

@@ -32,7 +32,7 @@ def test_struct_layouts_match_header():
     from ubresnet_amd import _lib as L
     assert C.sizeof(L.Tensor) == 32 and C.sizeof(L.ChanAffine) == 32
     # int32 x5, Tensor, ChanAffine, ptr, int32 x3, 3x64 bytes, int32 x5, Tensor x2, ptr x2, int32 x2
-    assert C.sizeof(L.ConvDesc) == 20 + 4 + 32 + 32 + 8 + 12 + 192 + 20 + 64 + 16 + 8 + 8 + 8 + 32 + 32 + 8
+    assert C.sizeof(L.ConvDesc) == 20 + 4 + 32 + 32 + 8 + 12 + 192 + 20 + 64 + 16 + 8 + 8 + 8 + 32 + 32 + 40 + 64 + 8
     assert C.sizeof(L.WgradDesc) % 8 == 0
 
 

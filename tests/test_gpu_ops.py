@@ -215,6 +215,33 @@ def test_conv_training_epilogues(dt, shape):
 
 
 @pytest.mark.parametrize("dt", DTS + [torch.float16])
+@pytest.mark.parametrize("shape", [(2, 16, 16, 128, 64), (1, 8, 24, 512, 256), (2, 12, 20, 64, 64)])
+def test_conv_phases_equal_one_launch_per_phase(dt, shape):
+    """ubr_conv_desc.nphase: the four output phases of ConvTranspose2d(k4, s2, p1) -- and of the data gradient of a stride-2
+    3x3 conv, with an addend -- in ONE launch are bitwise the four launches (same kernel family, same cin-block order)."""
+    N, H, W, Cin, Cout = shape
+    x = nhwc(rnd(dt, gen(N, Cin, H, W, seed=31)), dt)
+    aff = Affine(lo_zero(Cin), (gen(Cin, seed=34).abs() + 0.5).to(DEV), (gen(Cin, seed=35) * 0.3).to(DEV), lo_zero(Cin))
+    for k, pad, seed, with_ad, xf in ((4, 1, 32, False, aff), (3, 1, 33, True, None)):
+        w = gen(Cout, Cin, k, k, seed=seed, scale=(2.0 / (k * k * Cin)) ** 0.5)
+        wp = ops.pack_weights(w.to(DEV), dt, Cout, Cin, Cin * k * k, k * k, k * k)
+        ad = nhwc(rnd(dt, gen(N, Cout, 2 * H, 2 * W, seed=36)), dt) if with_ad else None
+        ybuf = torch.full((N, 2 * H, 2 * W, Cout + 16), 3.0, dtype=dt, device=DEV)       # output as a channel slice
+        ya = ybuf[..., :Cout]
+        phases = [(ry, rx, ops.transposed_phase_taps(k, 1, pad, 2, ry, rx)) for ry in range(2) for rx in range(2)]
+        assert all(p[2] for p in phases)
+        for ry, rx, tp in phases:
+            ops.conv(x, wp, ya[:, ry::2, rx::2, :], tp, Cout, xf=xf, addend=ad[:, ry::2, rx::2, :] if with_ad else None)
+        assert ops.last_conv_kernel().startswith(("conv_igemm_kernel", "conv_pc_kernel", "conv_thin_kernel"))
+        yb = torch.full((N, 2 * H, 2 * W, Cout), float("nan"), dtype=dt, device=DEV)
+        ops.conv_phases(x, wp, yb[:, 0::2, 0::2, :], [t for p in phases for t in p[2]], Cout, phases=phases, y_full=yb, addend_full=ad, xf=xf)
+        torch.cuda.synchronize()
+        assert ops.last_conv_kernel().startswith("conv_igemm_kernel")
+        assert torch.equal(yb, ya.contiguous()), "k=%d" % k
+        assert (ybuf[..., Cout:].float() == 3.0).all()
+
+
+@pytest.mark.parametrize("dt", DTS + [torch.float16])
 @pytest.mark.parametrize("chans", [(32, 16), (128, 64)])
 def test_deconv_forward_and_grads(dt, chans):
     """ConvTranspose2d(k4,s2,p1) as 4 phases into a concat slice; its data and weight gradients."""

@@ -66,6 +66,8 @@ class ConvDesc(C.Structure):
         ("addend_mask", C.c_void_p),
         ("bnb_c", Tensor),
         ("bnb_mean", C.c_void_p), ("bnb_scale", C.c_void_p), ("bnb_shift", C.c_void_p), ("bnb_invstd", C.c_void_p),
+        ("nphase", C.c_int32), ("phase_tap0", C.c_int32 * 4), ("phase_ntaps", C.c_int32 * 4), ("pad3_", C.c_int32),
+        ("phase_yoff", C.c_int64 * 4), ("phase_aoff", C.c_int64 * 4),
         ("stats_slots", C.c_int32), ("pad2_", C.c_int32),
     ]
 

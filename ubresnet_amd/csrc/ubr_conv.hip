@@ -48,6 +48,9 @@ struct ConvK {
   const float *bmean, *bscale, *bshift, *binvstd;
   int nslots;                                    // stripes of `stats` in use
   int pair_store;                                // conv_igemm_kernel: 16-byte stores of fragment pairs
+  // several output phases in one launch (blockIdx.z; ubr_conv_desc.nphase): each has its own tap range, output and addend base
+  int ptap0[4], pnunits[4], psteps[4];
+  long pyoff[4], paoff[4];                       // bytes
   int8_t dy[UBR_MAX_TAPS], dx[UBR_MAX_TAPS];
   uint8_t wt[UBR_MAX_TAPS];
   unsigned long long* stamps;                    // diagnostic build (-DUBR_CONV_STAMPS): per-workgroup phase cycle sums
@@ -194,6 +197,11 @@ __global__ __launch_bounds__(256, ((NT == 4 && FW <= 2 && !PIPE) ? 4 : 2)) void 
   const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
 #endif
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, l16 = lane & 15;
+  // output phase of this workgroup (one phase unless the launch batches the phases of a transposed conv / stride-2 data gradient)
+  const int ph = blockIdx.z;
+  const int tap0 = k.ptap0[ph], p_nunits = k.pnunits[ph], p_steps = k.psteps[ph];
+  char* const yb = k.y + k.pyoff[ph];
+  const char* const adb = k.ad != nullptr ? k.ad + k.paoff[ph] : nullptr;
   int t = blockIdx.x;
   const int tx = t % k.tiles_x; t /= k.tiles_x;
   const int ty = t % k.tiles_y;
@@ -240,8 +248,8 @@ __global__ __launch_bounds__(256, ((NT == 4 && FW <= 2 && !PIPE) ? 4 : 2)) void 
   }
   for (int u = tid; u < 4 * k.steps; u += 256) {
     int off = 0;
-    if (u < k.nunits) {
-      const int tap = u >> k.lgUPB, c = u & (k.UPB - 1);
+    if (u < p_nunits) {
+      const int tap = tap0 + (u >> k.lgUPB), c = u & (k.UPB - 1);
       off = ((k.dy[tap] - k.dymin) * k.HW + (k.dx[tap] - k.dxmin)) * k.pixb + c * 16;
     }
     tbl[u] = off;
@@ -250,8 +258,8 @@ __global__ __launch_bounds__(256, ((NT == 4 && FW <= 2 && !PIPE) ? 4 : 2)) void 
   int* wsrc = tbl + 4 * k.steps;
   for (int u = tid; u < 4 * k.steps; u += 256) {
     int v = -1;
-    if (u < k.nunits) {
-      const int tap = u >> k.lgUPB, cc = u & (k.UPB - 1);
+    if (u < p_nunits) {
+      const int tap = tap0 + (u >> k.lgUPB), cc = u & (k.UPB - 1);
       v = ((int)k.wt[tap] * k.CU + cc) * k.Cout_pad;
     }
     wsrc[u] = v;
@@ -289,7 +297,7 @@ __global__ __launch_bounds__(256, ((NT == 4 && FW <= 2 && !PIPE) ? 4 : 2)) void 
     constexpr int HS = HS_P, WS = conv_pipe_wslots(NT);
     ubr_u4 wv[WS];
     const int c = tid & (k.UPB - 1);
-    const int nw = 4 * k.steps * TN;
+    const int nw = 4 * p_steps * TN;
     int woff[WS];
 #pragma unroll
     for (int u = 0; u < WS; ++u) {
@@ -389,7 +397,7 @@ __global__ __launch_bounds__(256, ((NT == 4 && FW <= 2 && !PIPE) ? 4 : 2)) void 
       UBR_STAMP(tB);
       if (blk + 1 < k.nblk) load_blk(blk + 1);
       UBR_STAMP(tL);
-      for (int s = 0; s < k.steps; ++s) {
+      for (int s = 0; s < p_steps; ++s) {
         const int off = tbl[4 * s + q];
         uint4 wf[NT];
 #pragma unroll
@@ -461,7 +469,7 @@ __global__ __launch_bounds__(256, ((NT == 4 && FW <= 2 && !PIPE) ? 4 : 2)) void 
     // batched (WB in flight per thread). ----
     {
       constexpr int WB = 8;
-      const int nw = 4 * k.steps * TN;
+      const int nw = 4 * p_steps * TN;
       const int boff = blk * k.UPB * k.Cout_pad + n0;
       for (int ib = tid; ib < nw; ib += 256 * WB) {
         uint4 v[WB];
@@ -483,7 +491,7 @@ __global__ __launch_bounds__(256, ((NT == 4 && FW <= 2 && !PIPE) ? 4 : 2)) void 
     }
     __syncthreads();
     // ---- MFMA over (tap, cin-unit) ----
-    for (int s = 0; s < k.steps; ++s) {
+    for (int s = 0; s < p_steps; ++s) {
       const int off = tbl[4 * s + q];
       uint4 wf[NT];
 #pragma unroll
@@ -534,9 +542,9 @@ __global__ __launch_bounds__(256, ((NT == 4 && FW <= 2 && !PIPE) ? 4 : 2)) void 
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
       }
-      if (k.ad != nullptr && valid && ch < k.Cout) {
+      if (adb != nullptr && valid && ch < k.Cout) {
         float a4[4];
-        load4<T>(k.ad + (long)n * k.a_sn + (long)oy * k.a_sy + (long)ox * k.a_sx + (long)ch * ESZ, a4);
+        load4<T>(adb + (long)n * k.a_sn + (long)oy * k.a_sy + (long)ox * k.a_sx + (long)ch * ESZ, a4);
         if (k.ad_mask != nullptr) {
           const unsigned mb = (unsigned)k.ad_mask[(((long)n * k.OH + oy) * k.OW + ox) * k.ad_mask_cu + ch / CPU] >> (ch % CPU);
 #pragma unroll
@@ -575,8 +583,8 @@ __global__ __launch_bounds__(256, ((NT == 4 && FW <= 2 && !PIPE) ? 4 : 2)) void 
         int oy_a, ox_a, oy_b, ox_b;
         const bool ok0 = finish(i, v0, oy_a, ox_a) && ch < k.Cout;
         const bool ok1 = finish(i + (FW > 1 ? 1 : 0), v1, oy_b, ox_b) && ch < k.Cout;
-        store_frag_pair<T>(k.y + (long)n * k.y_sn + (long)oy_a * k.y_sy + (long)ox_a * k.y_sx + (long)ch * ESZ,
-                           k.y + (long)n * k.y_sn + (long)oy_b * k.y_sy + (long)ox_b * k.y_sx + (long)ch * ESZ, ok0, ok1, v0, v1, q);
+        store_frag_pair<T>(yb + (long)n * k.y_sn + (long)oy_a * k.y_sy + (long)ox_a * k.y_sx + (long)ch * ESZ,
+                           yb + (long)n * k.y_sn + (long)oy_b * k.y_sy + (long)ox_b * k.y_sx + (long)ch * ESZ, ok0, ok1, v0, v1, q);
       }
     } else {
 #pragma unroll
@@ -586,7 +594,7 @@ __global__ __launch_bounds__(256, ((NT == 4 && FW <= 2 && !PIPE) ? 4 : 2)) void 
       const bool valid = finish(i, v, oy, ox);
       if (k.epilogue == 0) {
         if (valid && ch < k.Cout)
-          store4<T>(k.y + (long)n * k.y_sn + (long)oy * k.y_sy + (long)ox * k.y_sx + (long)ch * ESZ, v);
+          store4<T>(yb + (long)n * k.y_sn + (long)oy * k.y_sy + (long)ox * k.y_sx + (long)ch * ESZ, v);
       } else if (j == 0) {
         // fused LogSoftmax over the first Cout (<=16) channels, fp32 NCHW output
         float m = -3.0e38f;
@@ -1648,7 +1656,7 @@ int try_thin(const ConvK& c, dim3 grid, hipStream_t st, int* rc) {
   constexpr int TH = 4 * FW / TWF, TW = TWF * 16, TN = NT * 16;
   static const bool thin_on = [] { const char* e = getenv("UBR_CONV_THIN"); return !e || atoi(e) != 0; }();
   const int esz = 16 / ET<T>::CPU;
-  if (!thin_on || c.nblk != 1 || c.S != 1 || (c.UPB != 2 && c.UPB != 4)) return 0;
+  if (!thin_on || c.nblk != 1 || c.S != 1 || (c.UPB != 2 && c.UPB != 4) || grid.z > 1) return 0;
   // ROW7: the full 7x7 tap set over 16 input channels on the 16x32-pixel tile (see conv_thin_kernel)
   int map7[7][7];
   bool row7 = false;
@@ -1842,6 +1850,14 @@ int launch_T(int cfg, const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
 
 struct Plan { int cfg; size_t lds; int UPB, steps, HH, HW, pixb, wl_off, halo_off, red_off, xfc_off, tiles_x, tiles_y, pc_buf; };
 
+// taps a workgroup walks: all of them, or the largest phase of a phased launch
+static int eff_ntaps(const ubr_conv_desc* d) {
+  if (d->nphase <= 1) return d->ntaps;
+  int m = 0;
+  for (int p = 0; p < d->nphase && p < 4; ++p) m = d->phase_ntaps[p] > m ? d->phase_ntaps[p] : m;
+  return m;
+}
+
 static bool plan_tile(const ubr_conv_desc* d, int cfg, int TH, int TW, int TN, int dymin, int dymax, int dxmin, int dxmax, Plan* p) {
   if (d->Cout_pad % TN) return false;
   if (d->epilogue == 1 && TN != 16) return false;
@@ -1852,8 +1868,8 @@ static bool plan_tile(const ubr_conv_desc* d, int cfg, int TH, int TW, int TN, i
   // 65 KB weight slab per 4-unit cin block) overflow 80 KB of LDS with 4-unit blocks and run one workgroup per CU;
   // 2-unit blocks halve both images.  The rule depends on the LAYER only (never on the tile or the batch), so an
   // image's result does not depend on what it is batched with.
-  if (UPB == 4 && (d->S == 2 || d->ntaps >= 16)) UPB = 2;
-  const int nunits = d->ntaps * UPB;
+  if (UPB == 4 && (d->S == 2 || eff_ntaps(d) >= 16)) UPB = 2;
+  const int nunits = eff_ntaps(d) * UPB;
   const int steps = (nunits + 3) / 4;
   const int HH = (TH - 1) * d->S + 1 + (dymax - dymin);
   const int HW = (TW - 1) * d->S + 1 + (dxmax - dxmin);
@@ -1989,6 +2005,17 @@ extern "C" int ubr_conv(const ubr_conv_desc* d, void* stream) {
               "ubr_conv: bnb_c view must be aligned to 4 elements, the BatchNorm vectors to 16 bytes");
   }
   const bool train_epi = d->addend_mask != nullptr || d->bnb_c.p != nullptr;
+  const int nphase = d->nphase > 1 ? d->nphase : 1;
+  if (nphase > 1) {
+    UBR_CHECK(nphase <= 4 && d->epilogue == 0 && !train_epi && d->stats == nullptr, "ubr_conv: a phased launch takes 2..4 phases, NHWC output, no statistics or training epilogue");
+    int covered = 0;
+    for (int p = 0; p < nphase; ++p) {
+      UBR_CHECK(d->phase_ntaps[p] >= 1 && d->phase_tap0[p] == covered, "ubr_conv: phase tap ranges must tile [0, ntaps) in order");
+      covered += d->phase_ntaps[p];
+      UBR_CHECK(d->phase_yoff[p] % 4 == 0 && d->phase_aoff[p] % 4 == 0, "ubr_conv: phase offsets must keep 4-element alignment");
+    }
+    UBR_CHECK(covered == d->ntaps, "ubr_conv: phase tap ranges must tile [0, ntaps)");
+  }
   int dymin = 127, dymax = -128, dxmin = 127, dxmax = -128;
   for (int t = 0; t < d->ntaps; ++t) {
     dymin = d->dy[t] < dymin ? d->dy[t] : dymin; dymax = d->dy[t] > dymax ? d->dy[t] : dymax;
@@ -2023,7 +2050,7 @@ extern "C" int ubr_conv(const ubr_conv_desc* d, void* stream) {
       static const int pc_mode = [] { const char* e = getenv("UBR_CONV_PC"); return e ? atoi(e) : 1; }();   // 0 off, 1 selective, 2 every eligible layer
       const int nblk_pc = d->Cin / (4 * cpu);
       const bool pick = pc_mode == 2 || (pc_mode == 1 && (nblk_pc <= 2 || (long)d->OH * d->OW <= 256) && !(d->Cin == d->Cout_pad && nblk_pc == 2));
-      if (pick && !train_epi && d->Cout_pad % 64 == 0 && d->ntaps >= 4) {
+      if (pick && !train_epi && nphase == 1 && d->Cout_pad % 64 == 0 && d->ntaps >= 4) {
         Plan cand{}; bool any = false;
         const int wide[] = {0, 1}, narrow[] = {2, 3};
         const int* ord = d->OW >= 32 ? wide : narrow;
@@ -2038,7 +2065,7 @@ extern "C" int ubr_conv(const ubr_conv_desc* d, void* stream) {
       }
     }
     // thin layers (one cin block, <= 32 output channels): the largest tile the persistent conv_thin_kernel can take wins outright
-    if (d->Cout_pad <= 32) {
+    if (d->Cout_pad <= 32 && nphase == 1) {
       const int g = d->Cout_pad == 32 ? 1 : 2;
       for (int i = 0; i < 4 && !have; ++i) {
         const int cfg = order_by_nt[g][i];
@@ -2084,7 +2111,16 @@ extern "C" int ubr_conv(const ubr_conv_desc* d, void* stream) {
   k.ntaps = d->ntaps; k.S = d->S; k.iy0 = d->iy0; k.ix0 = d->ix0; k.OH = d->OH; k.OW = d->OW;
   k.dymin = dymin; k.dxmin = dxmin; k.HH = best.HH; k.HW = best.HW;
   k.tiles_x = best.tiles_x; k.tiles_y = best.tiles_y;
-  k.nunits = d->ntaps * best.UPB; k.steps = best.steps; k.pixb = best.pixb;
+  k.nunits = eff_ntaps(d) * best.UPB; k.steps = best.steps; k.pixb = best.pixb;
+  for (int p = 0; p < 4; ++p) {
+    const bool on = p < nphase;
+    const int nt = nphase > 1 ? (on ? d->phase_ntaps[p] : 0) : d->ntaps;
+    k.ptap0[p] = nphase > 1 && on ? d->phase_tap0[p] : 0;
+    k.pnunits[p] = nt * best.UPB;
+    k.psteps[p] = (nt * best.UPB + 3) / 4;
+    k.pyoff[p] = nphase > 1 && on ? d->phase_yoff[p] * (long)esz : 0;
+    k.paoff[p] = nphase > 1 && on ? d->phase_aoff[p] * (long)esz : 0;
+  }
   k.rw = (unsigned)(best.HW * best.UPB);
   k.rw_magic = (unsigned)((0x100000000ull + k.rw - 1) / k.rw);
   UBR_CHECK((long)d->H * k.x_sy < (1L << 31) && k.x_sx < (1L << 20), "ubr_conv: image too large for 32-bit offsets");
@@ -2115,7 +2151,7 @@ extern "C" int ubr_conv(const ubr_conv_desc* d, void* stream) {
   if (best.cfg >= 100) { const PcCfg& w = kPc[best.cfg - 100]; c = TileCfg{w.FW, 4, w.TWF}; tn = 64; }
   else { c = kCfgs[best.cfg]; tn = c.NT * 16; }
   g_last_conv_cfg[0] = c.FW; g_last_conv_cfg[1] = c.NT; g_last_conv_cfg[2] = c.TWF;
-  dim3 grid((unsigned)(best.tiles_x * best.tiles_y * d->N), (unsigned)(d->Cout_pad / tn));
+  dim3 grid((unsigned)(best.tiles_x * best.tiles_y * d->N), (unsigned)(d->Cout_pad / tn), (unsigned)nphase);
   if (best.cfg >= 100) {
     // persistent: one workgroup of 8 waves per CU walks the (cout tile, pixel tile) units
     static const int ncu = [] { hipDeviceProp_t pr; int dev = 0; return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }();

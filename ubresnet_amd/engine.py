@@ -51,6 +51,20 @@ _WG_MAIN_EVERY = int(_os.environ.get("UBR_WGRAD_MAIN_EVERY", "0"))
 _WG_AFTER = _os.environ.get("UBR_WGRAD_ORDER", "before") == "after"
 # train-mode forward: the finalize launches of a block's bn2 / bnpass are fused into the block tail kernel
 _TAIL_FIN = _os.environ.get("UBR_TAIL_FIN", "1") != "0"
+# the four output phases of a transposed conv / of a stride-2 conv's data gradient in ONE launch when the layer has at least this
+# many output channels (narrower layers run on the persistent thin kernel, one launch per phase)
+_PHASE_MIN_C = int(_os.environ.get("UBR_PHASE_MIN_C", "64"))
+
+
+def _phased(k, pad):
+    """[(ry, rx, taps)] of the non-empty output phases of a stride-2 transposed conv, and their concatenation"""
+    ph = [(ry, rx, ops.transposed_phase_taps(k, 1, pad, 2, ry, rx)) for ry in range(2) for rx in range(2)]
+    ph = [p for p in ph if p[2]]
+    return ph, [t for p in ph for t in p[2]]
+
+
+_PH4 = _phased(4, 1)
+_PH3 = _phased(3, 1)
 
 
 def _phase(t, ry, rx):
@@ -448,6 +462,9 @@ class Engine:
             taps = DG3 if k == 3 else (DG1 if k == 1 else DG7)
             ops.conv(g, wp, gx, taps, Cin, addend=addend, addend_mask=addend_mask, bnb=bnb, stats=stats)
         else:
+            if k == 3 and Cin >= _PHASE_MIN_C and len(_PH3[0]) == 4 and addend_mask is None and bnb is None:
+                ops.conv_phases(g, wp, _phase(gx, 0, 0), _PH3[1], Cin, phases=_PH3[0], y_full=gx, addend_full=addend)
+                return
             for ry in range(2):
                 for rx in range(2):
                     taps = ops.transposed_phase_taps(k, 1, pad, 2, ry, rx)
@@ -552,6 +569,9 @@ class Engine:
         """ConvTranspose2d(k4,s2,p1) of x into channels [0,Cd) of the concat buffer (4 output phases)."""
         wp = self.packed(dl.deconv.weight, dt, "tfwd")
         up = cat[..., :Cd]
+        if Cd >= _PHASE_MIN_C and len(_PH4[0]) == 4:
+            ops.conv_phases(x, wp, _phase(up, 0, 0), _PH4[1], Cd, phases=_PH4[0], y_full=up, xf=xf_x)
+            return
         for ry in range(2):
             for rx in range(2):
                 ops.conv(x, wp, _phase(up, ry, rx), ops.transposed_phase_taps(4, 1, 1, 2, ry, rx), Cd, xf=xf_x)
@@ -1145,9 +1165,12 @@ class Engine:
     def _declayer_infer(self, dl, x, cat, Cd, out, img, fb, dt):
         wp = img[(id(dl.deconv.weight), "tfwd")]
         up = cat[..., :Cd]
-        for ry in range(2):
-            for rx in range(2):
-                ops.conv(x, wp, _phase(up, ry, rx), ops.transposed_phase_taps(4, 1, 1, 2, ry, rx), Cd)
+        if Cd >= _PHASE_MIN_C:
+            ops.conv_phases(x, wp, _phase(up, 0, 0), _PH4[1], Cd, phases=_PH4[0], y_full=up)
+        else:
+            for ry in range(2):
+                for rx in range(2):
+                    ops.conv(x, wp, _phase(up, ry, rx), ops.transposed_phase_taps(4, 1, 1, 2, ry, rx), Cd)
         self._double_infer(dl.res, cat, out, img, fb, dt)
 
     def uresnet_infer(self, x, dt):

@@ -268,6 +268,50 @@ def conv(x: torch.Tensor, wp: torch.Tensor, y: torch.Tensor, taps, Cout: int, S:
     L.check(L.lib().ubr_conv(C.byref(d), L.stream_ptr()), "conv")
 
 
+@_timed("conv")
+def conv_phases(x: torch.Tensor, wp: torch.Tensor, y0: torch.Tensor, taps, Cout: int, phases=None, y_full: torch.Tensor = None,
+                addend_full: Optional[torch.Tensor] = None, xf: Optional[Affine] = None, bias: Optional[torch.Tensor] = None):
+    """The output phases of a stride-2 transposed conv (or of the data gradient of a stride-2 conv) in ONE launch.
+    y_full: the whole NHWC output [N, 2*OH, 2*OW, Cout]; y0 = y_full[:, 0::2, 0::2, :] (passed for the launch labels);
+    phases: [(ry, rx, taps_of_phase)], taps = their concatenation; addend_full: optional tensor of y_full's shape."""
+    d = L.ConvDesc()
+    d.dtype = L.dtype_id(x.dtype)
+    N, H, W, Cin = x.shape
+    d.N, d.H, d.W, d.Cin = N, H, W, Cin
+    d.x = _tv(x)
+    d.xf = _xf(xf)
+    d.w = wp.data_ptr()
+    d.Cout, d.Cout_pad = Cout, wp.shape[2]
+    if wp.shape[1] * wp.shape[3] != Cin:
+        raise RuntimeError("conv: packed weights expect %d input channels, tensor has %d" % (wp.shape[1] * wp.shape[3], Cin))
+    if not 1 <= len(taps) <= L.MAX_TAPS or not 2 <= len(phases) <= 4:
+        raise RuntimeError("conv_phases: %d taps / %d phases unsupported" % (len(taps), len(phases)))
+    dy_a, dx_a, wt_a, wt_max = _tap_arrays(taps)
+    C.memmove(d.dy, dy_a, len(taps)); C.memmove(d.dx, dx_a, len(taps)); C.memmove(d.wt, wt_a, len(taps))
+    if wt_max >= wp.shape[0]:
+        raise RuntimeError("conv: tap index %d outside packed image" % wt_max)
+    d.ntaps = len(taps)
+    d.S, d.iy0, d.ix0 = 1, 0, 0
+    assert y_full.dtype == x.dtype and y_full.shape[0] == N and y_full.shape[3] == Cout and y_full.shape[1] % 2 == 0 and y_full.shape[2] % 2 == 0
+    d.OH, d.OW = y_full.shape[1] // 2, y_full.shape[2] // 2
+    sn, sy, sx = y_full.stride(0), y_full.stride(1), y_full.stride(2)
+    d.y = L.Tensor(y_full.data_ptr(), sn, 2 * sy, 2 * sx)
+    if addend_full is not None:
+        assert addend_full.shape == y_full.shape and addend_full.dtype == y_full.dtype and addend_full.stride(3) == 1
+        an, ay, ax = addend_full.stride(0), addend_full.stride(1), addend_full.stride(2)
+        d.addend = L.Tensor(addend_full.data_ptr(), an, 2 * ay, 2 * ax)
+    d.bias = L.ptr(bias)
+    d.nphase = len(phases)
+    t0 = 0
+    for i, (ry, rx, tp) in enumerate(phases):
+        d.phase_tap0[i], d.phase_ntaps[i] = t0, len(tp)
+        t0 += len(tp)
+        d.phase_yoff[i] = ry * sy + rx * sx
+        d.phase_aoff[i] = (ry * ay + rx * ax) if addend_full is not None else 0
+    assert t0 == len(taps)
+    L.check(L.lib().ubr_conv(C.byref(d), L.stream_ptr()), "conv (phased)")
+
+
 class WgradWorkspace:
     """grow-only fp32 slab workspace shared by all weight-gradient launches of a backward pass"""
 
