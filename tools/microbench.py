@@ -26,7 +26,7 @@ def aff(C):
 
 cfgs = {"conv16": (512, 16, 16, 3), "conv32": (256, 32, 32, 3), "conv64": (128, 64, 64, 3), "conv7": (512, 16, 16, 7),
         "conv1x1": (512, 16, 32, 1), "conv1x1b": (512, 32, 16, 1), "conv128": (64, 128, 128, 3), "conv256": (32, 256, 256, 3), "conv512": (16, 512, 512, 3),
-        "wgrad16": (512, 16, 16, 3), "wgrad32": (256, 32, 32, 3), "wgrad64": (128, 64, 64, 3), "wgrad256": (32, 256, 256, 3), "wgradstem": (512, 16, 16, 7)}
+        "wgrad16": (512, 16, 16, 3), "wgrad32": (256, 32, 32, 3), "wgrad64": (128, 64, 64, 3), "wgrad128": (64, 128, 128, 3), "wgrad256": (32, 256, 256, 3), "wgrad512": (16, 512, 512, 3), "wgradstem": (512, 16, 16, 7)}
 if what.startswith("conv"):
     HW, Cin, Cout, k = cfgs[what]
     x, y = mk(N, HW, HW, Cin), torch.empty((N, HW, HW, Cout), dtype=dt, device=dev)

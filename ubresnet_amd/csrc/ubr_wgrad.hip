@@ -36,6 +36,7 @@ struct WgK {
   unsigned hw_magic;                             // ceil(2^32 / HW)
   int x_sy32, x_sx32, g_sy32, g_sx32;            // row / pixel strides in bytes (per-image offsets fit 31 bits)
   int n_cot, dbg;
+  int rowreuse;                                  // 3x3 unit-stride tap grid, stride 1, full-height tile: compute_tile reads every halo row once
   unsigned long long* stamps;     // diagnostic build (UBR_WGRAD_STAMPS): per-workgroup phase cycle sums
   int8_t dy[UBR_MAX_TAPS], dx[UBR_MAX_TAPS];
 };
@@ -236,6 +237,48 @@ __global__ __launch_bounds__(256, (TPG == 25 ? 2 : 1)) void wgrad_kernel(const W
     toff[t] = (t0 + t < k.ntaps) ? ((k.dy[t0 + t] - k.dymin) * k.HW + (k.dx[t0 + t] - k.dxmin)) * k.pixbX : 0;
 
   auto compute_tile = [&]() {
+    // ---- 3x3 layers, 16-bit types: input row i of the halo feeds output rows i, i-1 and i-2 (vertical taps 0, 1, 2), so a wave
+    // that owns CONSECUTIVE output rows reads each halo row's three column-shifted fragments once and keeps a three-row window
+    // of gradient fragments: (R + 2) * 3 * NBW + R * MA fragment reads for R rows instead of R * (9 * NBW + MA).  The MFMA
+    // phase of these kernels is bound by the ds_read_b64_tr_b16 rate, not by the matrix pipe (in-kernel stamps, wide tile at
+    // 16x128x128x64: 4.5 k cycles per 8-row tile for 2.3 k cycles of MFMA).  Every accumulator still sums its rows in
+    // ascending order, so the N-split kernels produce the same bits as the tap-by-tap loop below. ----
+    if constexpr (TPG == 9 && CPU == 8) {
+      constexpr int ROWS = NSPLIT ? (TALL ? 8 : 4) : wgrad_kth(NSPLIT, TPG, MA, NB) / 4;
+      if (k.rowreuse) {
+        const int r0 = NSPLIT ? 0 : wave * ROWS;
+        const char* pa = gl + (r0 * 32 + 4 * q + (l16 >> 2)) * k.pixbG + (l16 & 3) * 8;
+        int xrow = ((r0 * k.HW) + 4 * q + (l16 >> 2)) * k.pixbX + (l16 & 3) * 8 + nb0 * 32;
+        asm volatile("" : "+v"(xrow));
+        const int arow = 32 * k.pixbG, brow = k.HW * k.pixbX;
+        uint4 Aw[3][MA];
+#pragma unroll
+        for (int i = 0; i < ROWS + 2; ++i) {
+          if (i < ROWS) {
+#pragma unroll
+            for (int a = 0; a < MA; ++a) Aw[i % 3][a] = tr_frag16(pa + i * arow + a * 32, 16 * k.pixbG);
+          }
+          uint4 B[3][NBW];
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+            for (int b = 0; b < NBW; ++b) B[dx][b] = tr_frag16(xl + (xrow + i * brow + toff[dx] + b * 32), 16 * k.pixbX);
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy) {
+            const int r = i - dy;
+            if (r >= 0 && r < ROWS) {
+#pragma unroll
+              for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                for (int b = 0; b < NBW; ++b)
+#pragma unroll
+                  for (int a = 0; a < MA; ++a) acc[dy * 3 + dx][a][b] = mma_step<T>(acc[dy * 3 + dx][a][b], B[dx][b], Aw[r % 3][a]);
+            }
+          }
+        }
+        return;
+      }
+    }
     // ---- MFMA: K-split: wave takes rows wave, wave+4, ...; N-split: every wave takes every row ----
 #ifdef UBR_WGRAD_STAMPS
     const int nrows = (k.dbg & 2) ? 1 : k.TH;
@@ -648,6 +691,13 @@ extern "C" int ubr_wgrad(const ubr_wgrad_desc* d, void* stream) {
   UBR_CHECK((long)d->H * k.x_sy < (1L << 31) && (long)d->GH * k.g_sy < (1L << 31), "ubr_wgrad: image too large for 32-bit offsets");
   k.x_sy32 = (int)k.x_sy; k.x_sx32 = (int)k.x_sx; k.g_sy32 = (int)k.g_sy; k.g_sx32 = (int)k.g_sx;
   k.n_cot = d->Cout / (p.MA * 16);
+  {
+    static const int rr = [] { const char* e = getenv("UBR_WGRAD_ROWREUSE"); return e ? atoi(e) : 1; }();
+    const int rows_full = p.nsplit_mode ? (wgrad_tall(true, p.TPG, p.MA) ? 8 : 4) : wgrad_kth(false, p.TPG, p.MA, p.NB);
+    bool grid3 = rr && d->ntaps == 9 && d->S == 1 && esz == 2 && p.TH == rows_full;
+    for (int t = 0; grid3 && t < 9; ++t) grid3 = d->dy[t] == dymin + t / 3 && d->dx[t] == dxmin + t % 3;
+    k.rowreuse = grid3 ? 1 : 0;
+  }
 #ifdef UBR_WGRAD_STAMPS     // diagnostic builds only
   { static const int dbg = [] { const char* e = getenv("UBR_WGRAD_DBG"); return e ? atoi(e) : 0; }(); k.dbg = dbg; }
   { static const char* sp = getenv("UBR_WGRAD_STAMP_PTR"); k.stamps = sp ? (unsigned long long*)strtoull(sp, nullptr, 0) : nullptr; }
