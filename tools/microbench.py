@@ -85,8 +85,18 @@ elif what.startswith("wgrad"):
         os.environ["UBR_WGRAD_STAMP_PTR"] = str(stamps.data_ptr())     # read once by a -DUBR_WGRAD_STAMPS build
         fn = lambda: L.check(L.lib().ubr_wgrad(C.byref(d), L.stream_ptr()), "wgrad")
         import atexit
+        def ops_last_wgrad_pc():
+            return Cout % 64 == 0 and Cin % 64 == 0 and k == 3 and os.environ.get("UBR_WGRAD_PC", "1") != "0"
         def _dump():
             st = stamps.cpu().view(-1, 8)
+            if ops_last_wgrad_pc():
+                st = stamps.cpu().view(-1, 16)
+                st = st[st[:, 4] > 0].float()
+                if len(st):
+                    m = st.median(0).values
+                    print("pc stamps (median cycles per workgroup over %d WGs): consumer wave 0: barrier waits %d, compute %d, epilogue %d, total %d | producer wave 4: transform (+ load wait) %d, "
+                          "load issue %d, LDS writes %d, barrier waits %d, total %d" % (len(st), m[6], m[2], m[3], m[4], m[8], m[9], m[10], m[11], m[12]))
+                return
             st = st[st[:, 4] > 0]
             if len(st):
                 m = st.float().median(0).values

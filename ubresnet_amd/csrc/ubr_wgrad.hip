@@ -82,8 +82,13 @@ __host__ __device__ constexpr int wgrad_xslots(bool nsplit, int tpg, int nb, int
   return (bigx ? 12 : (wgrad_tall(nsplit, tpg, ma) ? 11 : (nsplit ? 7 : (tpg == 25 ? 5 : (wgrad_kth(nsplit, tpg, ma, nb) == 16 ? (nb == 1 ? 5 : 10) : (nb == 1 ? 3 : 6)))))) * (8 / cpu);
 }
 
-template <typename T, int MA, int NB, int TPG, bool NSPLIT, bool BIGX>
-__global__ __launch_bounds__(256, (TPG == 25 ? 2 : 1)) void wgrad_kernel(const WgK k) {
+// PC = true (the wide 3x3 tile, 16-bit types): 512 threads.  Waves 4-7 (producers) own the staging -- loads two tiles ahead into
+// two register sets, the BatchNorm transform IN registers, the LDS writes; waves 0-3 (consumers) own the accumulators and do
+// nothing but fragment reads and MFMAs.  With one wave per SIMD the staging of a tile (5.6 k cycles, 2 k of them the transform's
+// VALU work) and its MFMA phase (2.5 k) ran one after the other; as two waves per SIMD the transform and the load issue of tile
+// i+1 run under the MFMAs of tile i, and only the LDS writes (between the two barriers) stay exposed.
+template <typename T, int MA, int NB, int TPG, bool NSPLIT, bool BIGX, bool PC = false>
+__global__ __launch_bounds__(PC ? 512 : 256, (TPG == 25 ? 2 : 1)) void wgrad_kernel(const WgK k) {
   constexpr int NBW = NSPLIT ? NB / 4 : NB;     // cin fragments owned by one wave
   static_assert(!NSPLIT || NB % 4 == 0, "N-split needs a multiple of 4 cin fragments");
   constexpr int CPU = ET<T>::CPU;
@@ -97,7 +102,9 @@ __global__ __launch_bounds__(256, (TPG == 25 ? 2 : 1)) void wgrad_kernel(const W
   char* gl = smem;
   char* xl = smem + k.x_off;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, l16 = lane & 15;
+  const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, q = lane >> 4, l16 = lane & 15;
+  const int tid = threadIdx.x & 255;             // staging thread id (PC: of the producer waves) / wave = consumer wave id
+  const bool producer = PC && threadIdx.x >= 256;
   const int cot = blockIdx.y % k.n_cot, cit = blockIdx.y / k.n_cot;
   const int co0 = cot * TCO, ci0 = cit * TCI;
   const int t0 = blockIdx.z * TPG;
@@ -133,7 +140,7 @@ __global__ __launch_bounds__(256, (TPG == 25 ? 2 : 1)) void wgrad_kernel(const W
   // SIMD, every variant but the 25-tap one): with one workgroup per CU nothing else hides a load, and one tile's MFMA phase
   // (72 MFMAs per wave, ~0.5 us) is shorter than a round trip to HBM under load -- the wide 9-tap kernel spent more time
   // waiting for the next tile than computing.
-  constexpr bool DEEP = TPG != 25 && !TALL;
+  constexpr bool DEEP = TPG != 25 && (!TALL || PC);
   u32x4_t gvA[GS], xvA[XS], gvB[DEEP ? GS : 1], xvB[DEEP ? XS : 1];
   unsigned xokA = 0u, xokB = 0u;
 
@@ -172,6 +179,9 @@ __global__ __launch_bounds__(256, (TPG == 25 ? 2 : 1)) void wgrad_kernel(const W
     st_tx = tt % k.tiles_x; tt /= k.tiles_x; st_ty = tt % k.tiles_y; st_n = tt / k.tiles_y;
   }
   auto load_tile = [&](auto& gv, auto& xv, unsigned& xok) {
+#ifdef UBR_WGRAD_STAMPS
+    if (k.dbg & 16) return;
+#endif
     const int tx = nx_tx, ty = nx_ty, n = nx_n;
     nx_tx += st_tx; nx_ty += st_ty; nx_n += st_n;
     if (nx_tx >= k.tiles_x) { nx_tx -= k.tiles_x; nx_ty += 1; }
@@ -208,7 +218,22 @@ __global__ __launch_bounds__(256, (TPG == 25 ? 2 : 1)) void wgrad_kernel(const W
   char* const xl_w = xl + px0 * k.pixbX + cx * 16;
   const int ginc = PGS * k.pixbG, xinc = PXS_T * k.pixbX;
   const int gfull = npxG / PGS, grem = npxG % PGS, xfull = npxX / PXS_T, xrem = npxX % PXS_T;
-  auto store_tile = [&](const auto& gv, const auto& xv, unsigned xok) {
+  auto xform_tile = [&](auto& xv, unsigned xok) {      // PC producers: the transform alone, in registers
+    if (!has_xf) return;
+#ifdef UBR_WGRAD_STAMPS
+    if (k.dbg & 8) return;
+#endif
+#pragma unroll
+    for (int u = 0; u < XS; ++u) {
+      float f[CPU];
+      ET<T>::unpack(make_uint4(xv[u].x, xv[u].y, xv[u].z, xv[u].w), f);
+      ubr_bnrelu<CPU>(f, xsub, xsc, xsh, xlo);
+      const uint4 t4 = ET<T>::pack(f);
+      const bool ok = (xok >> u) & 1u;
+      xv[u].x = ok ? t4.x : 0u; xv[u].y = ok ? t4.y : 0u; xv[u].z = ok ? t4.z : 0u; xv[u].w = ok ? t4.w : 0u;
+    }
+  };
+  auto store_tile = [&](const auto& gv, const auto& xv, unsigned xok, bool raw = false) {
 #ifdef UBR_WGRAD_STAMPS
     if (k.dbg & 4) return;
 #endif
@@ -218,7 +243,7 @@ __global__ __launch_bounds__(256, (TPG == 25 ? 2 : 1)) void wgrad_kernel(const W
 #pragma unroll
     for (int u = 0; u < XS; ++u) {
       u32x4_t v = xv[u];
-      if (has_xf) {
+      if (has_xf && !raw) {
         float f[CPU];
         ET<T>::unpack(make_uint4(v.x, v.y, v.z, v.w), f);
         ubr_bnrelu<CPU>(f, xsub, xsc, xsh, xlo);
@@ -347,6 +372,53 @@ __global__ __launch_bounds__(256, (TPG == 25 ? 2 : 1)) void wgrad_kernel(const W
 #else
 #define UBR_STAMP(acc_) do { } while (0)
 #endif
+  if constexpr (PC) {
+    if (producer) {
+      if (cur < k.ntiles) load_tile(gvA, xvA, xokA);
+      if (cur + G < k.ntiles) load_tile(gvB, xvB, xokB);
+      UBR_STAMP(tL);
+      while (cur < k.ntiles) {
+        xform_tile(xvA, xokA);
+        UBR_STAMP(tS);
+        __syncthreads();     // the consumers are done with the previous tile
+        UBR_STAMP(tB);
+        store_tile(gvA, xvA, xokA, true);
+        UBR_STAMP(tW);
+        __syncthreads();     // tile complete in LDS
+        UBR_STAMP(tB);
+        if (cur + 2 * G < k.ntiles) load_tile(gvA, xvA, xokA);
+        UBR_STAMP(tL);
+        cur += G;
+        if (cur >= k.ntiles) break;
+        xform_tile(xvB, xokB);
+        UBR_STAMP(tS);
+        __syncthreads();
+        UBR_STAMP(tB);
+        store_tile(gvB, xvB, xokB, true);
+        UBR_STAMP(tW);
+        __syncthreads();
+        UBR_STAMP(tB);
+        if (cur + 2 * G < k.ntiles) load_tile(gvB, xvB, xokB);
+        UBR_STAMP(tL);
+        cur += G;
+      }
+#ifdef UBR_WGRAD_STAMPS
+      if (k.stamps != nullptr && threadIdx.x == 256) {     // producer wave 4: transform (incl. waiting for the loads), barriers, LDS writes, load issue
+        unsigned long long* o = k.stamps + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + 8;
+        o[0] = tS; o[1] = tL; o[2] = tW; o[3] = tB; o[4] = t_ - t_begin;
+      }
+#endif
+      return;                // (the slab is written by the consumers; no barrier follows the tile loop)
+    }
+    while (cur < k.ntiles) {
+      __syncthreads();
+      __syncthreads();
+      UBR_STAMP(tB);
+      compute_tile();
+      UBR_STAMP(tC);
+      cur += G;
+    }
+  } else {
   if (cur < k.ntiles) load_tile(gvA, xvA, xokA);
   if constexpr (DEEP) {
     if (cur + G < k.ntiles) load_tile(gvB, xvB, xokB);
@@ -394,6 +466,7 @@ __global__ __launch_bounds__(256, (TPG == 25 ? 2 : 1)) void wgrad_kernel(const W
       cur = next;
       compute_tile();
     }
+  }
   }
 
   float* slab = k.slabs + (long)blockIdx.x * k.ntaps * k.Cout_pad * k.Cin;
@@ -447,7 +520,7 @@ __global__ __launch_bounds__(256, (TPG == 25 ? 2 : 1)) void wgrad_kernel(const W
 #ifdef UBR_WGRAD_STAMPS
   if (k.stamps != nullptr && tid == 0) {
     const unsigned long long t_end = __builtin_amdgcn_s_memtime();
-    unsigned long long* o = k.stamps + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8;
+    unsigned long long* o = k.stamps + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (PC ? 16 : 8);
     o[0] = tS; o[1] = tL; o[2] = tC; o[3] = t_end - t_; o[4] = t_end - t_begin; o[5] = t_begin; o[6] = tB; o[7] = tW;
   }
 #endif
@@ -542,9 +615,9 @@ static int wgrad_plan(const ubr_wgrad_desc* d, WPlan* p) {
   return UBR_OK;
 }
 
-template <typename T, int MA, int NB, int TPG, bool NSPLIT, bool BIGX = false>
+template <typename T, int MA, int NB, int TPG, bool NSPLIT, bool BIGX = false, bool PC = false>
 int wlaunch(const WgK& k, const WPlan& p, hipStream_t st) {
-  auto fn = wgrad_kernel<T, MA, NB, TPG, NSPLIT, BIGX>;
+  auto fn = wgrad_kernel<T, MA, NB, TPG, NSPLIT, BIGX, PC>;
   if (p.lds > 64 * 1024) {
     static thread_local size_t maxset = 0;
     if (p.lds > maxset) {
@@ -553,7 +626,7 @@ int wlaunch(const WgK& k, const WPlan& p, hipStream_t st) {
       maxset = p.lds;
     }
   }
-  ubr_launch(fn, dim3(p.nsplit, p.gy, p.gz), dim3(256), p.lds, st, k);
+  ubr_launch(fn, dim3(p.nsplit, p.gy, p.gz), dim3(PC ? 512 : 256), p.lds, st, k);
   UBR_LAUNCH_CHECK("ubr_wgrad");
   return UBR_OK;
 }
@@ -563,6 +636,10 @@ int wdispatch(const WgK& k, const WPlan& p, hipStream_t st) {
   if (p.bigx && !p.nsplit_mode && p.MA == 1 && p.TPG == 9) {
     if (p.NB == 1) return wlaunch<T, 1, 1, 9, false, true>(k, p, st);
     if (p.NB == 2) return wlaunch<T, 1, 2, 9, false, true>(k, p, st);
+  }
+  if constexpr (sizeof(T) == 2) {
+    static const int pc = [] { const char* e = getenv("UBR_WGRAD_PC"); return e ? atoi(e) : 1; }();
+    if (pc && !p.bigx && p.nsplit_mode && p.MA == 2 && p.NB == 4 && p.TPG == 9) return wlaunch<T, 2, 4, 9, true, false, true>(k, p, st);
   }
 #define UBR_WCASE(ma, nb, tpg) if (!p.bigx && !p.nsplit_mode && p.MA == ma && p.NB == nb && p.TPG == tpg) return wlaunch<T, ma, nb, tpg, false>(k, p, st);
 #define UBR_NCASE(ma, tpg) if (!p.bigx && p.nsplit_mode && p.MA == ma && p.NB == 4 && p.TPG == tpg) return wlaunch<T, ma, 4, tpg, true>(k, p, st);
