@@ -54,6 +54,8 @@ if what.startswith("conv"):
         if len(st):
             m = st.float().median(0).values
             print("   prologue %d, main loop %d, epilogue %d cycles (medians)" % ((st[:, 5] - st[:, 7]).float().median(), (st[:, 8] - st[:, 5]).float().median(), (st[:, 9] - st[:, 8]).float().median()))
+            print("   epilogue of wave 0: values + stores issued %d, statistics (wave sums, LDS, atomics) %d, waiting for the other waves %d"
+                  % ((st[:, 12] - st[:, 11]).float().median(), (st[:, 13] - st[:, 12]).float().median(), (st[:, 9] - st[:, 13]).float().median()))
             print("stamps (median cycles of wave 0 per workgroup, %d WGs): barriers %d, load wait %d, transform+LDS store %d, load issue %d, mfma loop %d, thin-kernel epilogue %d, main loop total %d"
                   % (len(st), m[3], m[6], m[0], m[1], m[2], m[10], m[4]))
     atexit.register(_dump)

@@ -48,6 +48,7 @@ struct ConvK {
   const float *bmean, *bscale, *bshift, *binvstd;
   int nslots;                                    // stripes of `stats` in use
   int pair_store;                                // conv_igemm_kernel: 16-byte stores of fragment pairs
+  int fast_epi;                                  // conv_igemm_kernel: per-image output / addend extents fit 31-bit offsets (buffer-addressed epilogue)
   // several output phases in one launch (blockIdx.z; ubr_conv_desc.nphase): each has its own tap range, output and addend base
   int ptap0[4], pnunits[4], psteps[4];
   long pyoff[4], paoff[4];                       // bytes
@@ -176,6 +177,8 @@ template <typename T> __device__ __forceinline__ void store_frag_pair(char* p0, 
     if (odd ? ok1 : ok0) *reinterpret_cast<uint4*>(p) = v;
   }
 }
+
+typedef __attribute__((ext_vector_type(2))) unsigned ubr_u2;
 
 template <typename T, int FW, int NT, int TWF, bool PIPE>
 __global__ __launch_bounds__(256, ((NT == 4 && FW <= 2 && !PIPE) ? 4 : 2)) void conv_igemm_kernel(const ConvK k) {
@@ -507,6 +510,9 @@ __global__ __launch_bounds__(256, ((NT == 4 && FW <= 2 && !PIPE) ? 4 : 2)) void 
   }
 
   // ---------------------------------- epilogue ----------------------------------
+#ifdef UBR_CONV_STAMPS
+  const unsigned long long te0 = __builtin_amdgcn_s_memtime();
+#endif
   float bs[NT][4];
 #pragma unroll
   for (int j = 0; j < NT; ++j)
@@ -521,6 +527,102 @@ __global__ __launch_bounds__(256, ((NT == 4 && FW <= 2 && !PIPE) ? 4 : 2)) void 
 #pragma unroll
     for (int r = 0; r < 4; ++r) { s1[j][r] = 0.f; s2[j][r] = 0.f; }
 
+  // Buffer-addressed epilogue (plain output, no BatchNorm-backward sums): beside an MFMA-bound wave of the other resident workgroup
+  // every VALU instruction of this phase costs ~10 cycles, and the general form below spends ~25 of its ~40 instructions per store
+  // on 64-bit addresses and per-fragment tests (in-kernel stamps, 16x128x128x64 -> 64: 11 k of the workgroup's 47 k cycles were
+  // "values + stores").  Here a store's address is one per-lane offset computed once plus a SCALAR fragment offset; lanes outside the
+  // output (ragged tiles, padded channels) get an out-of-range offset, which drops the store / returns a zero addend; all addend and
+  // mask loads are issued before the first value is finished.  Same arithmetic per value, in the same order.
+  if (k.fast_epi && k.epilogue == 0 && k.bc == nullptr && !(FW % 2 == 0 && sizeof(T) == 2 && k.pair_store)) {
+    constexpr int kOut = (int)0x80000000;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const bool full = (ox0 + TW <= k.OW) && (oy0 + TH <= k.OH) && (n0 + TN <= k.Cout);
+    const int ysx = (int)k.y_sx, ysy = (int)k.y_sy, asx = (int)k.a_sx, asy = (int)k.a_sy;
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(yb + (long)n * k.y_sn + (long)oy0 * k.y_sy + (long)ox0 * k.y_sx + (long)n0 * ESZ), 0, 0x7fffffff, 0x00020000);
+    const bool has_ad = adb != nullptr, has_mask = has_ad && k.ad_mask != nullptr;
+    const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(has_ad ? adb + (long)n * k.a_sn + (long)oy0 * k.a_sy + (long)ox0 * k.a_sx + (long)n0 * ESZ : k.x), 0, has_ad ? 0x7fffffff : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(has_mask ? (const char*)k.ad_mask + (((long)n * k.OH + oy0) * k.OW + ox0) * k.ad_mask_cu + n0 / CPU : k.x), 0, has_mask ? 0x7fffffff : 0, 0x00020000);
+    const int lane_y = l16 * ysx + 4 * q * ESZ, lane_a = l16 * asx + 4 * q * ESZ, lane_m = l16 * k.ad_mask_cu + (4 * q) / CPU;
+    // per fragment: scalar offsets and (ragged tiles only) the lane's validity
+    int so_y[FW], so_a[FW], so_m[FW];
+    bool okp[FW];        // pixel inside the output
+#pragma unroll
+    for (int i = 0; i < FW; ++i) {
+      const int f = wv * FW + i, fr = f / TWF, fc = f % TWF;
+      so_y[i] = fr * ysy + fc * 16 * ysx; so_a[i] = fr * asy + fc * 16 * asx; so_m[i] = (fr * k.OW + fc * 16) * k.ad_mask_cu;
+      okp[i] = full || ((oy0 + fr < k.OH) && (ox0 + fc * 16 + l16 < k.OW));
+    }
+    bool okc[NT];        // channel group inside Cout
+#pragma unroll
+    for (int j = 0; j < NT; ++j) okc[j] = full || (n0 + j * 16 + 4 * q < k.Cout);
+    ubr_u4 adv[FW][NT];  // raw addend: 8 bytes (16-bit types) or 16
+    unsigned admk[FW][NT];
+    if (has_ad) {
+#pragma unroll
+      for (int i = 0; i < FW; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int vo = (okp[i] && okc[j]) ? lane_a : kOut;
+          if constexpr (sizeof(T) == 2) {
+            const auto t2 = __builtin_amdgcn_raw_buffer_load_b64(ar, vo, so_a[i] + j * 16 * ESZ, 0);
+            adv[i][j] = ubr_u4{t2[0], t2[1], 0u, 0u};
+          } else {
+            adv[i][j] = __builtin_amdgcn_raw_buffer_load_b128(ar, vo, so_a[i] + j * 16 * ESZ, 0);
+          }
+          if (has_mask) admk[i][j] = __builtin_amdgcn_raw_buffer_load_b8(mr, (okp[i] && okc[j]) ? lane_m : kOut, so_m[i] + j * (16 / CPU), 0);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+#pragma unroll
+      for (int i = 0; i < FW; ++i) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bs[j][r];
+        if (k.act & 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        if (has_ad) {
+          float a4[4];
+          if constexpr (sizeof(T) == 2) {
+            const uint2 raw = make_uint2(adv[i][j][0], adv[i][j][1]);
+            load4<T>(reinterpret_cast<const char*>(&raw), a4);
+          } else {
+            a4[0] = __uint_as_float(adv[i][j][0]); a4[1] = __uint_as_float(adv[i][j][1]); a4[2] = __uint_as_float(adv[i][j][2]); a4[3] = __uint_as_float(adv[i][j][3]);
+          }
+          if (has_mask) {
+            const unsigned mb = (admk[i][j] & 0xffu) >> ((4 * q) % CPU);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a4[r] = ((mb >> r) & 1u) ? a4[r] : 0.f;
+          }
+          if (okp[i] && okc[j]) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += a4[r];
+          }
+        }
+        if (k.act & 2) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        if (k.stats != nullptr && okp[i]) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { s1[j][r] += v[r]; s2[j][r] += v[r] * v[r]; }
+        }
+        const int vo = (okp[i] && okc[j]) ? lane_y : kOut;
+        if constexpr (sizeof(T) == 2) {
+          uint2 pk;
+          store4<T>(reinterpret_cast<char*>(&pk), v);
+          __builtin_amdgcn_raw_buffer_store_b64(ubr_u2{pk.x, pk.y}, yr, vo, so_y[i] + j * 16 * ESZ, 0);
+        } else {
+          __builtin_amdgcn_raw_buffer_store_b128(ubr_u4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, yr, vo, so_y[i] + j * 16 * ESZ, 0);
+        }
+      }
+    }
+  } else
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int ch = n0 + j * 16 + 4 * q;
@@ -619,6 +721,9 @@ __global__ __launch_bounds__(256, ((NT == 4 && FW <= 2 && !PIPE) ? 4 : 2)) void 
     }
   }
 
+#ifdef UBR_CONV_STAMPS
+  const unsigned long long te1 = __builtin_amdgcn_s_memtime();
+#endif
   if (k.stats != nullptr) {
 #pragma unroll
     for (int j = 0; j < NT; ++j)
@@ -646,8 +751,12 @@ __global__ __launch_bounds__(256, ((NT == 4 && FW <= 2 && !PIPE) ? 4 : 2)) void 
   }
 #ifdef UBR_CONV_STAMPS
   if (PIPE && k.stamps != nullptr) {
+    const unsigned long long te2 = __builtin_amdgcn_s_memtime();
     __syncthreads();
-    if (tid == 0) k.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + 9] = __builtin_amdgcn_s_memtime();
+    if (tid == 0) {
+      unsigned long long* o = k.stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16;
+      o[9] = __builtin_amdgcn_s_memtime(); o[11] = te0; o[12] = te1; o[13] = te2;
+    }
   }
 #endif
 }
@@ -670,8 +779,6 @@ __global__ __launch_bounds__(256, ((NT == 4 && FW <= 2 && !PIPE) ? 4 : 2)) void 
 //   * <= 128 VGPRs: four workgroups per CU alone, and two beside the 240-VGPR weight-gradient kernels of the side stream
 //     (the 165-VGPR kernel dropped to ONE workgroup per CU there).
 // ---------------------------------------------------------------------------------------------
-typedef __attribute__((ext_vector_type(2))) unsigned ubr_u2;
-
 struct ThinK {
   const char* x; long x_sn; int x_sy, x_sx; unsigned x_bytes;
   const float *in_sub, *in_scale, *in_shift, *in_lo;
@@ -2144,6 +2251,12 @@ extern "C" int ubr_conv(const ubr_conv_desc* d, void* stream) {
 #endif
   k.wide_store = wide_ok ? 1 : 0;
   { static const bool pairs = [] { const char* e = getenv("UBR_CONV_PAIRS"); return e && atoi(e) != 0; }(); k.pair_store = (wide_ok && pairs) ? 1 : 0; }
+  {
+    static const bool fe = [] { const char* e = getenv("UBR_CONV_FAST_EPI"); return !e || atoi(e) != 0; }();
+    // (offsets are relative to the tile origin: at most a tile's rows times the row pitch)
+    const long lim = 1L << 26;
+    k.fast_epi = (fe && k.y_sy < lim && (k.ad == nullptr || k.a_sy < lim) && (long)k.OW * k.ad_mask_cu < lim) ? 1 : 0;
+  }
   for (int t = 0; t < d->ntaps; ++t) { k.dy[t] = d->dy[t]; k.dx[t] = d->dx[t]; k.wt[t] = d->wt[t]; }
 
   TileCfg c{};
