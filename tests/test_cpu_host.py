@@ -273,3 +273,19 @@ def test_bench_self_launches_two_ranks_dry_run():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["dry_run"] is True and d["exchange_ok"] is True
     assert d["config"]["global_batch"] == 32 and d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak"
+
+
+def test_no_16_byte_buffer_store_with_scalar_offset_in_the_built_library():
+    """gfx950 + hipcc 7.2: a buffer_store_dwordx3/x4 with an SGPR soffset gets no wait state before a VALU write to its data
+    registers, and the store then sends corrupted data (ubresnet_amd/csrc/ubr_conv.hip, buf_store16).  The sources fold scalar
+    offsets into the vector offset for such stores; scan the device code of the library build() produced to keep it that way."""
+    import importlib.util
+    lib = os.path.join(REPO, "ubresnet_amd", "libubresnet_hip.so")
+    if not os.path.exists(lib) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("library not built / llvm-objdump not present")
+    spec = importlib.util.spec_from_file_location("check_store_hazard", os.path.join(REPO, "tools", "check_store_hazard.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    total, bad = mod.scan(lib)
+    assert total > 100, "no device code found in %s" % lib
+    assert not bad, "16-byte buffer stores with an SGPR soffset: %s" % bad[:4]

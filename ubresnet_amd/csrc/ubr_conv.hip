@@ -86,9 +86,7 @@ template <> __device__ __forceinline__ void load4<f16_t>(const char* p, float* v
 template <typename T> __device__ __forceinline__ void round4(const float* v, float* r);
 template <> __device__ __forceinline__ void round4<float>(const float* v, float* r) { r[0] = v[0]; r[1] = v[1]; r[2] = v[2]; r[3] = v[3]; }
 template <> __device__ __forceinline__ void round4<bf16_t>(const float* v, float* r) {
-  // round-to-nearest-even on the bit pattern (integer ops; NaN kept as NaN), the result v_cvt_pk_bf16_f32 gives.  A compiler-placed
-  // v_cvt_pk_bf16_f32 next to the hand-scheduled convert + v_permlane16_swap block of the store path reproduced that block's
-  // known failure (lanes 12-15 of the even quads, second dword) in the variants that round here as well.
+  // round-to-nearest-even on the bit pattern (integer ops; NaN kept as NaN): the result v_cvt_pk_bf16_f32 gives
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const uint32_t u = __float_as_uint(v[i]);
@@ -139,10 +137,9 @@ __host__ __device__ constexpr int conv_pipe_hslots(int fw, int twf) { return ((4
 __host__ __device__ constexpr int conv_pipe_wslots(int nt) { return (36 * nt * 16 + 255) / 256; }
 
 // Two pixel fragments' 4-channel groups (fp32) -> this lane's 16 output bytes after the quad exchange (see store_pair16).
-// bf16: converts and swaps in ONE asm statement with early-clobber outputs, so that no convert's destination is a source of
-// its neighbours.  hipcc allocated  v35 <- cvt(v36,v37); v36 <- cvt(v30,v31); v37 <- cvt(...)  back to back, and on gfx950
-// the second convert's result then came out wrong in lanes 12-15 of every row (channels 2-3 / 10-11 of every second pixel
-// row; the f16 build, whose registers happened not to overlap, was correct).  Wait states by hand: hipcc pads nothing in asm.
+// bf16: converts and swaps in ONE asm statement with early-clobber outputs; wait states by hand (hipcc pads nothing inside asm).
+// (The wrong lanes 12-15 once seen after this block were the 16-byte store hazard described at buf_store16: a convert writing the
+// data registers of the store issued just before it.)
 template <typename T> __device__ __forceinline__ uint4 pack_swap_pair(const float* v0, const float* v1);
 template <> __device__ __forceinline__ uint4 pack_swap_pair<bf16_t>(const float* v0, const float* v1) {
   uint2 X, Y;
@@ -179,6 +176,18 @@ template <typename T> __device__ __forceinline__ void store_frag_pair(char* p0, 
 }
 
 typedef __attribute__((ext_vector_type(2))) unsigned ubr_u2;
+
+// 16-byte buffer store with a scalar offset.  gfx950 reads a store's data registers over several cycles; a VALU write to them in the
+// next instruction slot corrupts what the store sends (observed: the second dword of lanes 12-15 of each 16-lane row).  hipcc (ROCm 7.2)
+// inserts the wait state for stores wider than 8 bytes only when soffset is NOT an SGPR (it assumes the scalar operand fetch hides the
+// hazard -- it does not on this part: ISA of the fp32 epilogues, `buffer_store_dwordx4 v[96:99], v135, s[24:27], s90 offen` directly
+// followed by `v_pk_add_f32 v[96:97], ...`).  So 16-byte stores fold the scalar offset into the vector one (one v_add) and leave
+// soffset zero, which puts them under the compiler's own hazard handling; 8-byte stores are not affected.  (This is what the "stale
+// lanes 12-15" failures of the training epilogues in round 3 were; they had first been put down to MFMA result latency and to a
+// v_cvt_pk_bf16_f32 next to v_permlane16_swap.)
+__device__ __forceinline__ void buf_store16(const ubr_u4& v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, voff + soff, 0, 0);
+}
 
 template <typename T, int FW, int NT, int TWF, bool PIPE>
 __global__ __launch_bounds__(256, ((NT == 4 && FW <= 2 && !PIPE) ? 4 : 2)) void conv_igemm_kernel(const ConvK k) {
@@ -618,7 +627,7 @@ __global__ __launch_bounds__(256, ((NT == 4 && FW <= 2 && !PIPE) ? 4 : 2)) void 
           store4<T>(reinterpret_cast<char*>(&pk), v);
           __builtin_amdgcn_raw_buffer_store_b64(ubr_u2{pk.x, pk.y}, yr, vo, so_y[i] + j * 16 * ESZ, 0);
         } else {
-          __builtin_amdgcn_raw_buffer_store_b128(ubr_u4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, yr, vo, so_y[i] + j * 16 * ESZ, 0);
+          buf_store16(ubr_u4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, yr, vo, so_y[i] + j * 16 * ESZ);
         }
       }
     }
@@ -1152,11 +1161,6 @@ __global__ __launch_bounds__(256, ((ROW7 || (EXT == 1 && NT == 2)) ? 2 : 3)) voi
           for (int j = 0; j < NT; ++j) acc[i][j] = mma_step<T>(acc[i][j], wf[j], a[i]);
       }
       }   // !ROW7
-      // The accumulators are read right below.  Variants of this kernel with more registers in flight (the training epilogues)
-      // stored stale values in lanes 12-15 of every 16-lane row -- the columns an MFMA's LAST pass writes -- for the accumulator
-      // of the last-issued MFMA: the matrix result had not landed when the first VALU read it.  Two s_nop 15 cover the longest
-      // MFMA here (8 passes); they cost ~30 cycles per 72..448 MFMAs.
-      asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
       UBR_TSTAMP(tC);
 
       // ---- epilogue of this fragment group ----
@@ -1221,12 +1225,12 @@ __global__ __launch_bounds__(256, ((ROW7 || (EXT == 1 && NT == 2)) ? 2 : 3)) voi
             } else if constexpr (WIDE) {
               const uint4 pk = pack_swap_pair<T>(v[0], v[1]);
               ubr_u4 o = {pk.x, pk.y, pk.z, pk.w};
-              __builtin_amdgcn_raw_buffer_store_b128(o, yr, vo_out[j], so, 0);
+              buf_store16(o, yr, vo_out[j], so);
             } else {
 #pragma unroll
               for (int h = 0; h < 2; ++h) {
                 ubr_u4 o = {__float_as_uint(v[h][0]), __float_as_uint(v[h][1]), __float_as_uint(v[h][2]), __float_as_uint(v[h][3])};
-                __builtin_amdgcn_raw_buffer_store_b128(o, yr, vo_out[j] + h * 16 * k.y_sx, so, 0);
+                buf_store16(o, yr, vo_out[j] + h * 16 * k.y_sx, so);
               }
             }
           } else if (j == 0) {
@@ -1655,6 +1659,84 @@ __global__ __launch_bounds__(512) void conv_pc_kernel(const ConvK k) {
             const int ch = n0 + j * 16 + 4 * q + r;
             bs[j][r] = (k.bias != nullptr && ch < k.Cout) ? k.bias[ch] : 0.f;
           }
+        if (k.fast_epi) {
+          // buffer-addressed form (see conv_igemm_kernel's epilogue): one per-lane offset, scalar fragment offsets, addend loads up front
+          constexpr int kOut = (int)0x80000000;
+          const int wv = __builtin_amdgcn_readfirstlane(wave);
+          const bool full = (ox0 + TW <= k.OW) && (oy0 + TH <= k.OH) && (n0 + TN <= k.Cout);
+          const int ysx = (int)k.y_sx, ysy = (int)k.y_sy, asx = (int)k.a_sx, asy = (int)k.a_sy;
+          const bool has_ad = k.ad != nullptr;
+          const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(
+              (void*)(k.y + (long)n * k.y_sn + (long)oy0 * k.y_sy + (long)ox0 * k.y_sx + (long)n0 * ESZ), 0, 0x7fffffff, 0x00020000);
+          const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(
+              (void*)(has_ad ? k.ad + (long)n * k.a_sn + (long)oy0 * k.a_sy + (long)ox0 * k.a_sx + (long)n0 * ESZ : k.x), 0, has_ad ? 0x7fffffff : 0, 0x00020000);
+          const int lane_y = l16 * ysx + 4 * q * ESZ, lane_a = l16 * asx + 4 * q * ESZ;
+          int so_y[FW], so_a[FW];
+          bool okp[FW], okc[NT];
+#pragma unroll
+          for (int i2 = 0; i2 < FW; ++i2) {
+            const int f = wv * FW + i2, fr = f / TWF, fc = f % TWF;
+            so_y[i2] = fr * ysy + fc * 16 * ysx; so_a[i2] = fr * asy + fc * 16 * asx;
+            okp[i2] = full || ((oy0 + fr < k.OH) && (ox0 + fc * 16 + l16 < k.OW));
+          }
+#pragma unroll
+          for (int j = 0; j < NT; ++j) okc[j] = full || (n0 + j * 16 + 4 * q < k.Cout);
+          ubr_u4 adv[FW][NT];
+          if (has_ad) {
+#pragma unroll
+            for (int i2 = 0; i2 < FW; ++i2)
+#pragma unroll
+              for (int j = 0; j < NT; ++j) {
+                const int vo = (okp[i2] && okc[j]) ? lane_a : kOut;
+                if constexpr (sizeof(T) == 2) {
+                  const auto t2 = __builtin_amdgcn_raw_buffer_load_b64(ar, vo, so_a[i2] + j * 16 * ESZ, 0);
+                  adv[i2][j] = ubr_u4{t2[0], t2[1], 0u, 0u};
+                } else {
+                  adv[i2][j] = __builtin_amdgcn_raw_buffer_load_b128(ar, vo, so_a[i2] + j * 16 * ESZ, 0);
+                }
+              }
+          }
+#pragma unroll
+          for (int i2 = 0; i2 < FW; ++i2) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+              float v[4];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = acc[i2][j][r] + bs[j][r];
+              if (k.act & 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+              }
+              if (has_ad && okp[i2] && okc[j]) {
+                float a4[4];
+                if constexpr (sizeof(T) == 2) {
+                  const uint2 raw = make_uint2(adv[i2][j][0], adv[i2][j][1]);
+                  load4<T>(reinterpret_cast<const char*>(&raw), a4);
+                } else {
+                  a4[0] = __uint_as_float(adv[i2][j][0]); a4[1] = __uint_as_float(adv[i2][j][1]); a4[2] = __uint_as_float(adv[i2][j][2]); a4[3] = __uint_as_float(adv[i2][j][3]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += a4[r];
+              }
+              if (k.act & 2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+              }
+              if (k.stats != nullptr && okp[i2]) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { s1[j][r] += v[r]; s2[j][r] += v[r] * v[r]; }
+              }
+              const int vo = (okp[i2] && okc[j]) ? lane_y : kOut;
+              if constexpr (sizeof(T) == 2) {
+                uint2 pk;
+                store4<T>(reinterpret_cast<char*>(&pk), v);
+                __builtin_amdgcn_raw_buffer_store_b64(ubr_u2{pk.x, pk.y}, yr, vo, so_y[i2] + j * 16 * ESZ, 0);
+              } else {
+                buf_store16(ubr_u4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, yr, vo, so_y[i2] + j * 16 * ESZ);
+              }
+            }
+          }
+        } else
 #pragma unroll
         for (int i2 = 0; i2 < FW; ++i2) {
           const int f = wave * FW + i2;
@@ -1804,10 +1886,6 @@ int try_thin(const ConvK& c, dim3 grid, hipStream_t st, int* rc) {
   // training epilogues: BatchNorm-backward sums (EXT 1) or a ReLU bit mask on the addend (EXT 2); never both (ubr_conv checks)
   const int ext = c.bc != nullptr ? 1 : (c.ad_mask != nullptr ? 2 : 0);
   if (ext != 0 && (c.in_scale != nullptr || c.epilogue != 0)) return 0;
-  // fp32 with the masked addend: this variant of the kernel computes channel 1 of one fragment wrongly in lanes 12-15 of every
-  // quad (independent of the mask values and of how the gating is written; 16-bit variants and the other epilogues are
-  // bit-exact against the generic kernel) -- the parity path takes the generic kernel instead
-  if (ext == 2 && sizeof(T) == 4) return 0;
   k.nslots = c.nslots;
   if (ext == 1) {
     if (c.bc_sy >= (1L << 24) || (long)c.OH * c.bc_sy >= (1L << 31)) return 0;
