@@ -197,6 +197,18 @@ void ubr_wgrad_last_config(int* ma, int* nb, int* tpg, int* nsplit_mode, int* bi
 int ubr_wgrad_reduce(float* slabs /* clobbered */, int nsplit, int ntaps, int Cout_pad, int Cin,
                      int Cout_valid, int Cin_valid, float* dst, int64_t sm, int64_t sk,
                      const int32_t* tapidx_host, int accumulate, void* stream);
+/* Several weight gradients' slab sums in ONE launch (the 73 sums of a U-ResNet backward pass were 73 launches of a few
+ * microseconds each on the weight-gradient stream): item i is exactly ubr_wgrad_reduce's argument list; per element the same
+ * additions in the same order, so the results are bit-identical to nitems single calls.  At most UBR_REDUCE_BATCH items per call. */
+#define UBR_REDUCE_BATCH 16
+typedef struct {
+  float* slabs;
+  float* dst;
+  int32_t nsplit, ntaps, Cout_pad, Cin, Cout_valid, Cin_valid, accumulate, pad_;
+  int64_t sm, sk;
+  int32_t tapidx[UBR_MAX_TAPS];
+} ubr_wgrad_reduce_item;
+int ubr_wgrad_reduce_batched(const ubr_wgrad_reduce_item* items_host, int nitems, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Stem: conv1 7x7 s1 p3 + bias on the caller's NCHW fp32 image (models/ub_uresnet.py:41,94;

@@ -244,6 +244,7 @@ def test_aspp_level_backward_tie_free():
         o = eng.grad_offsets[name]
         views[id(p)] = flat[o:o + p.numel()].view(p.shape)
     g_e = eng.aspp_level_bwd(rec, nh(g_post), nh(g_base), lambda p: views[id(p)])
+    eng._wg_flush()        # (a whole backward pass sums the weight-gradient slabs once per stage: Engine._stage_notifier)
     torch.cuda.synchronize()
     # oracle
     p = OrderedDict((k, v.clone().requires_grad_(True) if O.is_param_key(k) else v.clone()) for k, v in sd.items())

@@ -54,6 +54,7 @@ def _run(eng, fwd, bwd, go):
         o = eng.grad_offsets[name]
         views[id(p)] = flat[o:o + p.numel()].view(p.shape)
     gx = bwd(rec, lambda p: views[id(p)])
+    eng._wg_flush()        # (a whole backward pass sums the weight-gradient slabs once per stage: Engine._stage_notifier)
     torch.cuda.synchronize()
     return gx, {name: views[id(p)].cpu() for name, p in eng.grad_order}
 
@@ -195,6 +196,7 @@ def test_stem_on_matrix_cores(cfg, dt):
         o = eng.grad_offsets[name]
         views[id(p)] = flat[o:o + p.numel()].view(p.shape)
     eng.stem_bwd(st.conv1, x16, go.permute(0, 2, 3, 1).contiguous().to(dt).to(DEV), lambda p: views[id(p)])
+    eng._wg_flush()
     torch.cuda.synchronize()
     assert _rel(views[id(st.conv1.weight)].cpu(), wr.grad) <= 4 * tol
     assert _rel(views[id(st.conv1.bias)].cpu(), br.grad) <= 4 * tol

@@ -82,6 +82,19 @@ class BnFwdFin(C.Structure):
     ]
 
 
+REDUCE_BATCH = 16         # UBR_REDUCE_BATCH
+
+
+class WgradReduceItem(C.Structure):
+    _fields_ = [
+        ("slabs", C.c_void_p), ("dst", C.c_void_p),
+        ("nsplit", C.c_int32), ("ntaps", C.c_int32), ("Cout_pad", C.c_int32), ("Cin", C.c_int32),
+        ("Cout_valid", C.c_int32), ("Cin_valid", C.c_int32), ("accumulate", C.c_int32), ("pad_", C.c_int32),
+        ("sm", C.c_int64), ("sk", C.c_int64),
+        ("tapidx", C.c_int32 * 64),
+    ]
+
+
 class WgradDesc(C.Structure):
     _fields_ = [
         ("dtype", C.c_int32),
@@ -101,7 +114,7 @@ class WgradDesc(C.Structure):
 
 # every symbol include/ubresnet_hip.h declares (tests check that all of them are exported)
 SYMBOLS = [
-    "ubr_conv", "ubr_conv_last_config", "ubr_conv_last_kernel", "ubr_pack_weights", "ubr_pack_weights_batched", "ubr_bn_fold_batched", "ubr_wgrad_plan", "ubr_wgrad", "ubr_wgrad_last_config", "ubr_wgrad_reduce",
+    "ubr_conv", "ubr_conv_last_config", "ubr_conv_last_kernel", "ubr_pack_weights", "ubr_pack_weights_batched", "ubr_bn_fold_batched", "ubr_wgrad_plan", "ubr_wgrad", "ubr_wgrad_last_config", "ubr_wgrad_reduce", "ubr_wgrad_reduce_batched",
     "ubr_stem_forward", "ubr_stem_wgrad", "ubr_stem_wgrad_workspace", "ubr_stem_expand",
     "ubr_bn_finalize", "ubr_bn_eval_affine", "ubr_bn_bwd_reduce", "ubr_bn_bwd_finalize", "ubr_bn_bwd_apply",
     "ubr_block_tail_fwd", "ubr_block_tail_bwd_reduce", "ubr_block_tail_bwd_apply",
@@ -136,6 +149,7 @@ def _declare(lib):
     lib.ubr_wgrad_plan.argtypes = [C.POINTER(WgradDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
     lib.ubr_wgrad.argtypes = [C.POINTER(WgradDesc), vp]
     lib.ubr_wgrad_reduce.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, i64, i64, C.POINTER(C.c_int32), i32, vp]
+    lib.ubr_wgrad_reduce_batched.argtypes = [C.POINTER(WgradReduceItem), i32, vp]
     lib.ubr_stem_forward.argtypes = [i32, vp, i32, i32, i32, i32, vp, vp, i32, Tensor, vp, vp]
     lib.ubr_stem_wgrad.argtypes = [i32, vp, i32, i32, i32, i32, Tensor, i32, vp, i64, vp, vp, i32, vp]
     lib.ubr_stem_expand.argtypes = [i32, vp, i32, i32, i32, i32, vp, i64, vp]

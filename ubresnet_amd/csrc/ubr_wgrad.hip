@@ -790,6 +790,100 @@ extern "C" int ubr_wgrad(const ubr_wgrad_desc* d, void* stream) {
   }
 }
 
+// ---- batched form: the items travel in the kernel arguments (no device table to upload or keep alive; a launch tape stores them by value)
+struct RedItem {
+  const float* slabs; float* dst;
+  int nsplit, ntaps, Cout_pad, Cin, Cout_valid, Cin_valid, accumulate, blocks;
+  long sm, sk;
+  uint8_t tapidx[UBR_MAX_TAPS];
+};
+struct RedBatch { int n, pad_; RedItem it[UBR_REDUCE_BATCH]; };
+static_assert(sizeof(RedBatch) <= 3072, "kernel argument budget");
+
+__global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const RedBatch b) {
+  __shared__ float part[4][64];
+  int it = 0, blk = (int)blockIdx.x;
+  while (it + 1 < b.n && blk >= b.it[it].blocks) { blk -= b.it[it].blocks; ++it; }     // (uniform: scalar loads from the argument segment)
+  const RedItem& k = b.it[it];
+  const long per = (long)k.ntaps * k.Cout_pad * k.Cin;
+  if (k.nsplit <= 8) {
+    for (long i = (long)blk * 256 + threadIdx.x; i < per; i += (long)k.blocks * 256) {
+      const int ci = (int)(i % k.Cin);
+      long r = i / k.Cin;
+      const int co = (int)(r % k.Cout_pad);
+      const int t = (int)(r / k.Cout_pad);
+      if (co >= k.Cout_valid || ci >= k.Cin_valid) continue;
+      float s = 0.f;
+#pragma unroll 8
+      for (int sp = 0; sp < k.nsplit; ++sp) s += k.slabs[(long)sp * per + i];
+      float* d = k.dst + (long)co * k.sm + (long)ci * k.sk + k.tapidx[t];
+      *d = k.accumulate ? (*d + s) : s;
+    }
+    return;
+  }
+  const int e = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const int q = (k.nsplit + 3) / 4;
+  const int s0 = sg * q, s1 = min(s0 + q, k.nsplit);
+  for (long base = (long)blk * 64; base < per; base += (long)k.blocks * 64) {
+    const long i = base + e;
+    float s = 0.f;
+    if (i < per) {
+      int sp = s0;
+      for (; sp + 8 <= s1; sp += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = k.slabs[(long)(sp + u) * per + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
+      for (; sp < s1; ++sp) s += k.slabs[(long)sp * per + i];
+    }
+    part[sg][e] = s;
+    __syncthreads();
+    if (sg == 0 && i < per) {
+      const int ci = (int)(i % k.Cin);
+      long r = i / k.Cin;
+      const int co = (int)(r % k.Cout_pad);
+      const int t = (int)(r / k.Cout_pad);
+      if (co < k.Cout_valid && ci < k.Cin_valid) {
+        const float tot = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
+        float* d = k.dst + (long)co * k.sm + (long)ci * k.sk + k.tapidx[t];
+        *d = k.accumulate ? (*d + tot) : tot;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int ubr_wgrad_reduce_batched(const ubr_wgrad_reduce_item* items, int nitems, void* stream) {
+  UBR_CHECK(items != nullptr && nitems >= 1 && nitems <= UBR_REDUCE_BATCH, "ubr_wgrad_reduce_batched: 1..%d items", UBR_REDUCE_BATCH);
+  RedBatch b{};
+  b.n = nitems;
+  long total = 0;
+  for (int i = 0; i < nitems; ++i) {
+    const ubr_wgrad_reduce_item& s = items[i];
+    UBR_CHECK(s.slabs && s.dst, "ubr_wgrad_reduce_batched: null pointer (item %d)", i);
+    UBR_CHECK(s.nsplit >= 1 && s.nsplit <= kRedMaxSplit && s.ntaps >= 1 && s.ntaps <= UBR_MAX_TAPS && s.Cout_pad > 0 && s.Cin > 0 &&
+              s.Cout_valid > 0 && s.Cout_valid <= s.Cout_pad && s.Cin_valid > 0 && s.Cin_valid <= s.Cin, "ubr_wgrad_reduce_batched: bad extents (item %d)", i);
+    RedItem& r = b.it[i];
+    r.slabs = s.slabs; r.dst = s.dst; r.nsplit = s.nsplit; r.ntaps = s.ntaps; r.Cout_pad = s.Cout_pad; r.Cin = s.Cin;
+    r.Cout_valid = s.Cout_valid; r.Cin_valid = s.Cin_valid; r.accumulate = s.accumulate; r.sm = s.sm; r.sk = s.sk;
+    for (int t = 0; t < s.ntaps; ++t) {
+      UBR_CHECK(s.tapidx[t] >= 0 && s.tapidx[t] < 256, "ubr_wgrad_reduce_batched: tap index %d out of range", s.tapidx[t]);
+      r.tapidx[t] = (uint8_t)s.tapidx[t];
+    }
+    const long per = (long)s.ntaps * s.Cout_pad * s.Cin;
+    const bool flat = s.nsplit <= 8;
+    long blocks = (per + (flat ? 255 : 63)) / (flat ? 256 : 64);      // (same grids as the single-item launches)
+    if (blocks > 8192) blocks = 8192;
+    r.blocks = (int)blocks;
+    total += blocks;
+  }
+  ubr_launch(wgrad_reduce_batched_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, b);
+  UBR_LAUNCH_CHECK("ubr_wgrad_reduce_batched");
+  return UBR_OK;
+}
+
 extern "C" int ubr_wgrad_reduce(float* slabs, int nsplit, int ntaps, int Cout_pad, int Cin,
                                 int Cout_valid, int Cin_valid, float* dst, int64_t sm, int64_t sk,
                                 const int32_t* tapidx_host, int accumulate, void* stream) {

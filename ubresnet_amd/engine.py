@@ -50,6 +50,7 @@ _WG_MAIN_EVERY = int(_os.environ.get("UBR_WGRAD_MAIN_EVERY", "0"))
 # operand (single-stream schedule: the operand is then still in L2 / MALL); default: before it (side stream: earliest start)
 _WG_AFTER = _os.environ.get("UBR_WGRAD_ORDER", "before") == "after"
 # train-mode forward: the finalize launches of a block's bn2 / bnpass are fused into the block tail kernel
+_DEFER_REDUCE = _os.environ.get("UBR_DEFER_REDUCE", "1") != "0"     # weight-gradient slab sums: one launch per backward stage
 _TAIL_FIN = _os.environ.get("UBR_TAIL_FIN", "1") != "0"
 # the four output phases of a transposed conv / of a stride-2 conv's data gradient in ONE launch when the layer has at least this
 # many output channels (narrower layers run on the persistent thin kernel, one launch per phase)
@@ -407,7 +408,14 @@ class Engine:
         prio = int(os.environ.get("UBR_SIDE_PRIORITY", "-1" if in_job else "0"))
         self.side = torch.cuda.Stream(device=dev, priority=prio)
 
+    def _wg_flush(self):
+        """one launch for the slab sums of every weight gradient issued since the last flush (ops.ReduceBatch)"""
+        b = self.__dict__.get("_red_batch")
+        if b is not None:
+            b.flush()
+
     def _side_end(self, dev):
+        self._wg_flush()
         if self._side_on:
             torch.cuda.current_stream(dev).wait_stream(self.side)
             self._fork(1, 0)
@@ -415,6 +423,11 @@ class Engine:
 
     def _wg(self, x, g, *args, **kw):
         self._wg_count += 1
+        if _DEFER_REDUCE and "defer" not in kw:
+            b = self.__dict__.get("_red_batch")
+            if b is None:
+                b = self.__dict__["_red_batch"] = ops.ReduceBatch(self.wws)
+            kw["defer"] = b
         if not self._side_on or (_WG_MAIN_EVERY > 0 and self._wg_count % _WG_MAIN_EVERY == 0):
             return ops.wgrad(x, g, *args, **kw)
         # side stream waits for everything queued on the compute stream so far (x and g are produced there); the
@@ -721,6 +734,7 @@ class Engine:
         ids = [id(p) for _, p in self.grad_order]
 
         def stage_done(last_param):
+            self._wg_flush()         # the stage's weight gradients are final only after their (batched) slab sums
             i = ids.index(id(last_param))
             hi = self.grad_offsets[self.grad_order[i][0]] + (self.grad_order[i][1].numel() + 3) // 4 * 4
             if self._rec is not None and hi > done[0]:

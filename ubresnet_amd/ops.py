@@ -328,6 +328,72 @@ class WgradWorkspace:
             self.buf = torch.empty(max(n, 1 << 20), dtype=torch.float32, device=device)
         return self.buf
 
+    # slabs that must outlive the launch (their sums are deferred to a batched reduction): a bump arena, reset by release()
+    def hold(self, nbytes: int, device) -> torch.Tensor:
+        n = ((nbytes + 3) // 4 + 63) // 64 * 64
+        a = getattr(self, "arena", None)
+        if a is None or a.device != device or self.arena_off + n > a.numel():
+            if a is not None:
+                self.arena_old.append(a)          # pending items still point into it
+            self.arena = a = torch.empty(max(2 * n, 64 << 20), dtype=torch.float32, device=device)
+            self.arena_off = 0
+        t = a[self.arena_off:self.arena_off + n]
+        self.arena_off += n
+        return t
+
+    def release(self):
+        self.arena_off = 0
+        if not self.pin:
+            self.arena_old.clear()
+
+    arena = None
+    arena_off = 0
+
+    @property
+    def arena_old(self):
+        if "_arena_old" not in self.__dict__:
+            self.__dict__["_arena_old"] = []
+        return self.__dict__["_arena_old"]
+
+
+class ReduceBatch:
+    """Weight-gradient slab sums deferred to ONE launch per group (ubr_wgrad_reduce_batched): `wgrad(..., defer=batch)` launches
+    the MFMA kernel only; `flush()` sums every pending item's slabs -- the same additions per element as ubr_wgrad_reduce."""
+
+    def __init__(self, ws: "WgradWorkspace"):
+        self.ws = ws
+        self.items = []          # (WgradReduceItem fields, slab bytes)
+        self.stream = None
+
+    def add(self, item, nbytes, stream):
+        assert not self.items or stream is self.stream, "a batch belongs to one stream"
+        self.stream = stream
+        self.items.append((item, nbytes))
+
+    def flush(self):
+        if not self.items:
+            return
+        lib = L.lib()
+        stream = self.stream
+        st = L.stream_ptr() if stream is None else stream.cuda_stream
+        sink = _rec_sink
+        for lo in range(0, len(self.items), L.REDUCE_BATCH):
+            chunk = self.items[lo:lo + L.REDUCE_BATCH]
+            arr = (L.WgradReduceItem * len(chunk))(*[c[0] for c in chunk])
+            if _prof is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+            lab = sink.label_begin() if sink is not None else -1
+            L.check(lib.ubr_wgrad_reduce_batched(arr, len(chunk), st), "wgrad_reduce_batched")
+            meta = ("wgrad_reduce", "wgrad_reduce_batched_kernel", "%d weight gradients" % len(chunk), sum(c[1] for c in chunk), 0.0)
+            if sink is not None:
+                sink.label_end(lab, meta)
+            if _prof is not None:
+                e1.record(stream)
+                _prof.records.append(meta + (e0, e1))
+        self.items = []
+        self.ws.release()
+
 
 _TAP_CACHE_W = {}
 
@@ -344,9 +410,13 @@ def _tap_arrays_w(taps):
 
 def wgrad(x: torch.Tensor, g: torch.Tensor, taps, dst: torch.Tensor, sm: int, sk: int, Cout_valid: int, Cin_valid: int,
           ws: WgradWorkspace, S: int = 1, iy0: int = 0, ix0: int = 0, xf: Optional[Affine] = None, accumulate: bool = False,
-          dst_offset: int = 0, stream=None, exclusive: bool = False):
+          dst_offset: int = 0, stream=None, exclusive: bool = False, defer: Optional["ReduceBatch"] = None):
     """dst[co*sm + ci*sk + tapidx] (+)= sum_pixels g[p][co] * xform(x)[p*S + tap][ci]
     taps: [(dy, dx, tapidx into the PyTorch weight layout)]; stream: torch.cuda.Stream to launch on (default: current)"""
+    if defer is not None and (accumulate or (defer.items and defer.stream is not stream)):
+        defer.flush()            # an accumulating sum must see the pending ones; a batch belongs to one stream
+        if accumulate:
+            defer = None
     d = L.WgradDesc()
     d.dtype = L.dtype_id(x.dtype)
     N, H, W, Cin = x.shape
@@ -364,7 +434,7 @@ def wgrad(x: torch.Tensor, g: torch.Tensor, taps, dst: torch.Tensor, sm: int, sk
     nsplit, nbytes = C.c_int32(0), C.c_int64(0)
     lib = L.lib()
     L.check(lib.ubr_wgrad_plan(C.byref(d), C.byref(nsplit), C.byref(nbytes)), "wgrad_plan")
-    slabs = ws.get(nbytes.value, x.device)
+    slabs = ws.get(nbytes.value, x.device) if defer is None else ws.hold(nbytes.value, x.device)
     if stream is not None:
         # the workspace is grow-only: when a later call replaces it, the caching allocator must not recycle the old block
         # for the compute stream while this (side-stream) launch still reads it
@@ -380,13 +450,23 @@ def wgrad(x: torch.Tensor, g: torch.Tensor, taps, dst: torch.Tensor, sm: int, sk
     L.check(lib.ubr_wgrad(C.byref(d), st), "wgrad")
     if _prof is not None:
         e1.record(stream)
-    lab1 = sink.label_begin() if sink is not None else -1
     idx = _tap_arrays_w(taps)[2]
     assert dst.dtype == torch.float32
-    L.check(lib.ubr_wgrad_reduce(slabs.data_ptr(), nsplit.value, len(taps), d.Cout, Cin, Cout_valid, Cin_valid,
-                                 dst.data_ptr() + 4 * dst_offset, sm, sk, idx, 1 if accumulate else 0, st), "wgrad_reduce")
+    lab1 = -1
+    if defer is not None:
+        it = L.WgradReduceItem()
+        it.slabs, it.dst = slabs.data_ptr(), dst.data_ptr() + 4 * dst_offset
+        it.nsplit, it.ntaps, it.Cout_pad, it.Cin, it.Cout_valid, it.Cin_valid = nsplit.value, len(taps), d.Cout, Cin, Cout_valid, Cin_valid
+        it.accumulate, it.sm, it.sk = 1 if accumulate else 0, sm, sk
+        for i in range(len(taps)):
+            it.tapidx[i] = idx[i]
+        defer.add(it, nsplit.value * len(taps) * d.Cout * Cin * 4, stream)
+    else:
+        lab1 = sink.label_begin() if sink is not None else -1
+        L.check(lib.ubr_wgrad_reduce(slabs.data_ptr(), nsplit.value, len(taps), d.Cout, Cin, Cout_valid, Cin_valid,
+                                     dst.data_ptr() + 4 * dst_offset, sm, sk, idx, 1 if accumulate else 0, st), "wgrad_reduce")
     if _prof is not None or sink is not None:
-        if _prof is not None:
+        if _prof is not None and defer is None:
             e2.record(stream)
         a, b, c, dd, bx = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
         lib.ubr_wgrad_last_config(C.byref(a), C.byref(b), C.byref(c), C.byref(dd), C.byref(bx))
@@ -398,10 +478,14 @@ def wgrad(x: torch.Tensor, g: torch.Tensor, taps, dst: torch.Tensor, sm: int, sk
         red = ("wgrad_reduce", "wgrad_reduce_kernel", sig, nsplit.value * len(taps) * d.Cout * Cin * 4, 0.0)
         if sink is not None:
             sink.labels[lab0] = ("wgrad", kern, sig, nbytes, flops)
-            sink.label_end(lab1, red)
+            if lab1 >= 0:
+                sink.label_end(lab1, red)
+            else:
+                sink.tape.set_label(-1)
         if _prof is not None:
             _prof.records.append(("wgrad", kern, sig, nbytes, flops, e0, e1))
-            _prof.records.append(red + (e1, e2))
+            if defer is None:
+                _prof.records.append(red + (e1, e2))
 
 
 # ------------------------------------------------------------------------------------------
