@@ -194,6 +194,7 @@ typedef struct {
 int ubr_wgrad_plan(const ubr_wgrad_desc* d, int32_t* nsplit, int64_t* workspace_bytes);
 int ubr_wgrad(const ubr_wgrad_desc* d, void* stream);
 void ubr_wgrad_last_config(int* ma, int* nb, int* tpg, int* nsplit_mode, int* bigx);   /* template arguments of wgrad_kernel */
+int ubr_wgrad_last_pc(void);   /* 1: that launch was the producer/consumer variant (wgrad_kernel's 7th template argument) */
 int ubr_wgrad_reduce(float* slabs /* clobbered */, int nsplit, int ntaps, int Cout_pad, int Cin,
                      int Cout_valid, int Cin_valid, float* dst, int64_t sm, int64_t sk,
                      const int32_t* tapidx_host, int accumulate, void* stream);

@@ -114,7 +114,7 @@ class WgradDesc(C.Structure):
 
 # every symbol include/ubresnet_hip.h declares (tests check that all of them are exported)
 SYMBOLS = [
-    "ubr_conv", "ubr_conv_last_config", "ubr_conv_last_kernel", "ubr_pack_weights", "ubr_pack_weights_batched", "ubr_bn_fold_batched", "ubr_wgrad_plan", "ubr_wgrad", "ubr_wgrad_last_config", "ubr_wgrad_reduce", "ubr_wgrad_reduce_batched",
+    "ubr_conv", "ubr_conv_last_config", "ubr_conv_last_kernel", "ubr_pack_weights", "ubr_pack_weights_batched", "ubr_bn_fold_batched", "ubr_wgrad_plan", "ubr_wgrad", "ubr_wgrad_last_config", "ubr_wgrad_last_pc", "ubr_wgrad_reduce", "ubr_wgrad_reduce_batched",
     "ubr_stem_forward", "ubr_stem_wgrad", "ubr_stem_wgrad_workspace", "ubr_stem_expand",
     "ubr_bn_finalize", "ubr_bn_eval_affine", "ubr_bn_bwd_reduce", "ubr_bn_bwd_finalize", "ubr_bn_bwd_apply",
     "ubr_block_tail_fwd", "ubr_block_tail_bwd_reduce", "ubr_block_tail_bwd_apply",
@@ -143,6 +143,8 @@ def _declare(lib):
     lib.ubr_conv_last_config.restype = None
     lib.ubr_wgrad_last_config.argtypes = [C.POINTER(C.c_int)] * 5
     lib.ubr_wgrad_last_config.restype = None
+    lib.ubr_wgrad_last_pc.argtypes = []
+    lib.ubr_wgrad_last_pc.restype = C.c_int
     lib.ubr_pack_weights.argtypes = [i32, vp, vp, i32, i32, i32, i32, i64, i64, i32, C.POINTER(C.c_int32), vp]
     lib.ubr_pack_weights_batched.argtypes = [i32, vp, i32, vp]
     lib.ubr_bn_fold_batched.argtypes = [vp, i32, vp]

@@ -99,6 +99,15 @@ __device__ __forceinline__ float ubr_vmax(float a, float b) {
   asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
+// Wave priority of the compute stream's kernels (s_setprio: instruction arbitration among the waves of a SIMD).  The weight-gradient
+// kernels of the side stream keep priority 0.
+#ifndef UBR_MAIN_PRIO
+#define UBR_MAIN_PRIO 3
+#endif
+__device__ __forceinline__ void ubr_main_prio() {
+  if constexpr (UBR_MAIN_PRIO > 0) __builtin_amdgcn_s_setprio(UBR_MAIN_PRIO);
+}
+
 template <int N>
 __device__ __forceinline__ void ubr_bnrelu(float* f, const float* sub, const float* sc, const float* sh, const float* lo) {
 #pragma unroll

@@ -191,6 +191,7 @@ __device__ __forceinline__ void buf_store16(const ubr_u4& v, __amdgpu_buffer_rsr
 
 template <typename T, int FW, int NT, int TWF, bool PIPE>
 __global__ __launch_bounds__(256, ((NT == 4 && FW <= 2 && !PIPE) ? 4 : 2)) void conv_igemm_kernel(const ConvK k) {
+  ubr_main_prio();
   constexpr int TN = NT * 16;
   constexpr int F = 4 * FW;
   constexpr int TH = F / TWF;
@@ -824,6 +825,7 @@ __device__ __forceinline__ unsigned udiv_magic(unsigned n, unsigned magic) { ret
 // taps share a row (56 virtual taps, the host supplies their table; the pad tap has zero weights): +12 % MFMAs.
 template <typename T, int FW, int NT, int TWF, int UPB, bool XF, bool LSM, bool ROW7 = false, int EXT = 0>
 __global__ __launch_bounds__(256, ((ROW7 || (EXT == 1 && NT == 2)) ? 2 : 3)) void conv_thin_kernel(const ThinK k) {
+  ubr_main_prio();
   static_assert(EXT == 0 || (!XF && !LSM), "the training epilogues belong to the data-gradient convs (no transform on load, NHWC output)");
   constexpr int TN = NT * 16;
   constexpr int TH = 4 * FW / TWF;

@@ -246,6 +246,7 @@ __device__ __forceinline__ void fwd_fin_site(const BnFwdFin& f, int nslots, int 
 }
 template <typename T, bool BYP, bool MASK>
 __global__ __launch_bounds__(256) void tail_fwd_kernel(const TailF k) {
+  ubr_main_prio();
   constexpr int CPU = ET<T>::CPU;
   constexpr int H2 = CPU / 2;
   constexpr int UNR = 4;
@@ -356,6 +357,7 @@ __device__ __forceinline__ void fin_site(const double* red, int nslots, int C, d
 
 template <typename T, bool APPLY, bool BYP, bool HAS_GO2, bool MASK>
 __global__ __launch_bounds__(256) void tail_bwd_kernel(const TailB k) {
+  ubr_main_prio();
   constexpr int CPU = ET<T>::CPU;
   constexpr int H2 = CPU / 2;
   constexpr int UNR = APPLY ? 2 : 4;
@@ -471,6 +473,7 @@ struct BnB {
 };
 template <typename T, bool APPLY, bool HAS_GA2, bool RELU>
 __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnB k) {
+  ubr_main_prio();
   constexpr int CPU = ET<T>::CPU;
   constexpr int H2 = CPU / 2;
   constexpr int UNR = 4;

@@ -631,6 +631,8 @@ int wlaunch(const WgK& k, const WPlan& p, hipStream_t st) {
   return UBR_OK;
 }
 
+static thread_local int g_last_wgrad_cfg[6] = {0, 0, 0, 0, 0, 0};   // MA, NB, TPG, N-split, wide staging, producer/consumer of this thread's last launch
+
 template <typename T>
 int wdispatch(const WgK& k, const WPlan& p, hipStream_t st) {
   if (p.bigx && !p.nsplit_mode && p.MA == 1 && p.TPG == 9) {
@@ -639,7 +641,7 @@ int wdispatch(const WgK& k, const WPlan& p, hipStream_t st) {
   }
   if constexpr (sizeof(T) == 2) {
     static const int pc = [] { const char* e = getenv("UBR_WGRAD_PC"); return e ? atoi(e) : 1; }();
-    if (pc && !p.bigx && p.nsplit_mode && p.MA == 2 && p.NB == 4 && p.TPG == 9) return wlaunch<T, 2, 4, 9, true, false, true>(k, p, st);
+    if (pc && !p.bigx && p.nsplit_mode && p.MA == 2 && p.NB == 4 && p.TPG == 9) { g_last_wgrad_cfg[5] = 1; return wlaunch<T, 2, 4, 9, true, false, true>(k, p, st); }
   }
 #define UBR_WCASE(ma, nb, tpg) if (!p.bigx && !p.nsplit_mode && p.MA == ma && p.NB == nb && p.TPG == tpg) return wlaunch<T, ma, nb, tpg, false>(k, p, st);
 #define UBR_NCASE(ma, tpg) if (!p.bigx && p.nsplit_mode && p.MA == ma && p.NB == 4 && p.TPG == tpg) return wlaunch<T, ma, 4, tpg, true>(k, p, st);
@@ -729,7 +731,7 @@ extern "C" int ubr_wgrad_plan(const ubr_wgrad_desc* d, int32_t* nsplit, int64_t*
   return UBR_OK;
 }
 
-static thread_local int g_last_wgrad_cfg[5] = {0, 0, 0, 0, 0};
+extern "C" int ubr_wgrad_last_pc(void) { return g_last_wgrad_cfg[5]; }     // 1: the last launch was the producer/consumer variant (7th template argument)
 extern "C" void ubr_wgrad_last_config(int* ma, int* nb, int* tpg, int* nsplit_mode, int* bigx) {
   if (ma) *ma = g_last_wgrad_cfg[0];
   if (nb) *nb = g_last_wgrad_cfg[1];
@@ -742,7 +744,7 @@ extern "C" int ubr_wgrad(const ubr_wgrad_desc* d, void* stream) {
   WPlan p{};
   int rc = wgrad_plan(d, &p);
   if (rc != UBR_OK) return rc;
-  g_last_wgrad_cfg[0] = p.MA; g_last_wgrad_cfg[1] = p.NB; g_last_wgrad_cfg[2] = p.TPG; g_last_wgrad_cfg[3] = p.nsplit_mode; g_last_wgrad_cfg[4] = p.bigx;
+  g_last_wgrad_cfg[0] = p.MA; g_last_wgrad_cfg[1] = p.NB; g_last_wgrad_cfg[2] = p.TPG; g_last_wgrad_cfg[3] = p.nsplit_mode; g_last_wgrad_cfg[4] = p.bigx; g_last_wgrad_cfg[5] = 0;
   const int esz = ubr_esize(d->dtype);
   UBR_CHECK(d->x.p && d->g.p && d->slabs, "ubr_wgrad: null tensor");
   UBR_CHECK(d->nsplit == p.nsplit, "ubr_wgrad: nsplit %d does not match plan %d", d->nsplit, p.nsplit);

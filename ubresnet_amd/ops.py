@@ -470,8 +470,8 @@ def wgrad(x: torch.Tensor, g: torch.Tensor, taps, dst: torch.Tensor, sm: int, sk
             e2.record(stream)
         a, b, c, dd, bx = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
         lib.ubr_wgrad_last_config(C.byref(a), C.byref(b), C.byref(c), C.byref(dd), C.byref(bx))
-        kern = "wgrad_kernel<%s, %d, %d, %d, %s, %s>" % (_DT_NAME[x.dtype], a.value, b.value, c.value, "true" if dd.value else "false",
-                                                         "true" if bx.value else "false")
+        kern = "wgrad_kernel<%s, %d, %d, %d, %s, %s, %s>" % (_DT_NAME[x.dtype], a.value, b.value, c.value, "true" if dd.value else "false",
+                                                             "true" if bx.value else "false", "true" if lib.ubr_wgrad_last_pc() else "false")
         sig = "%s %s taps%d S%d" % ("x".join(map(str, x.shape)), "x".join(map(str, g.shape)), len(taps), S)
         nbytes = (x.numel() + g.numel()) * x.element_size()
         flops = 2.0 * g.shape[0] * g.shape[1] * g.shape[2] * g.shape[3] * Cin * len(taps)
