@@ -1,4 +1,6 @@
 #!/bin/bash
-python -c "import torch; print('priority range', torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream,'priority_range') else None)"
-B="python bench.py --steps 40 --warmup 5 --no-infer --no-cpu-baseline --no-extra-legs --no-breakdown"
-for v in 0 1 -1 0 1 -1; do echo -n "side_priority=$v "; UBR_SIDE_PRIORITY=$v $B 2>&1 | python tools/benchline.py; done
+echo "== default"; python tools/reprocheck.py 3 2>/dev/null
+echo "== UBR_DEFER_REDUCE=0"; UBR_DEFER_REDUCE=0 python tools/reprocheck.py 3 2>/dev/null
+echo "== UBR_WGRAD_PC=0"; UBR_WGRAD_PC=0 python tools/reprocheck.py 3 2>/dev/null
+echo "== UBR_CONV_FAST_EPI=0"; UBR_CONV_FAST_EPI=0 python tools/reprocheck.py 3 2>/dev/null
+echo "== UBR_WGRAD_STREAM=0"; UBR_WGRAD_STREAM=0 python tools/reprocheck.py 3 2>/dev/null

@@ -27,9 +27,12 @@ def aff(C):
 cfgs = {"conv16": (512, 16, 16, 3), "conv32": (256, 32, 32, 3), "conv64": (128, 64, 64, 3), "conv7": (512, 16, 16, 7),
         "conv1x1": (512, 16, 32, 1), "conv1x1b": (512, 32, 16, 1), "conv128": (64, 128, 128, 3), "conv256": (32, 256, 256, 3), "conv512": (16, 512, 512, 3),
         "wgrad16": (512, 16, 16, 3), "wgrad32": (256, 32, 32, 3), "wgrad64": (128, 64, 64, 3), "wgrad128": (64, 128, 128, 3), "wgrad256": (32, 256, 256, 3), "wgrad512": (16, 512, 512, 3), "wgradstem": (512, 16, 16, 7)}
+cfgs.update({"conv32s2": (256, 32, 64, 3), "conv64s2": (128, 64, 128, 3), "conv128s2": (64, 128, 256, 3), "conv256s2": (32, 256, 512, 3),
+             "conv32s2k1": (256, 32, 64, 1), "conv64s2k1": (128, 64, 128, 1)})
 if what.startswith("conv"):
     HW, Cin, Cout, k = cfgs[what]
-    x, y = mk(N, HW, HW, Cin), torch.empty((N, HW, HW, Cout), dtype=dt, device=dev)
+    S = 2 if "s2" in what else 1
+    x, y = mk(N, HW, HW, Cin), torch.empty((N, HW // S, HW // S, Cout), dtype=dt, device=dev)
     w = torch.randn(Cout, Cin, k, k, device=dev) * 0.05
     wp = ops.pack_weights(w, dt, Cout, Cin, Cin * k * k, k * k, k * k)
     st = torch.zeros(32 * 2 * Cout, dtype=torch.float64, device=dev)
@@ -54,15 +57,19 @@ if what.startswith("conv"):
         if len(st):
             m = st.float().median(0).values
             print("   prologue %d, main loop %d, epilogue %d cycles (medians)" % ((st[:, 5] - st[:, 7]).float().median(), (st[:, 8] - st[:, 5]).float().median(), (st[:, 9] - st[:, 8]).float().median()))
+            if (st[:, 15] > 0).any():
+                print("   prologue of wave 0: entry -> halo loads issued %d, tap / weight-source tables built %d, first barrier %d, weight offsets + block-0 weight loads issued (+ constants to LDS) %d"
+                      % ((st[:, 10] - st[:, 7]).float().median(), (st[:, 14] - st[:, 10]).float().median(), (st[:, 15] - st[:, 14]).float().median(), (st[:, 5] - st[:, 15]).float().median()))
             print("   epilogue of wave 0: values + stores issued %d, statistics (wave sums, LDS, atomics) %d, waiting for the other waves %d"
                   % ((st[:, 12] - st[:, 11]).float().median(), (st[:, 13] - st[:, 12]).float().median(), (st[:, 9] - st[:, 13]).float().median()))
             print("stamps (median cycles of wave 0 per workgroup, %d WGs): barriers %d, load wait %d, transform+LDS store %d, load issue %d, mfma loop %d, thin-kernel epilogue %d, main loop total %d"
                   % (len(st), m[3], m[6], m[0], m[1], m[2], m[10], m[4]))
     atexit.register(_dump)
     ad = torch.zeros_like(y) if "addend" in sys.argv else None
-    fn = lambda: ops.conv(x, wp, y, ctaps, Cout, xf=xf, stats=stats, tile_hint=hint, addend=ad)
+    slots = max([int(a[5:]) for a in sys.argv if a.startswith("slots")] + [0])
+    fn = lambda: ops.conv(x, wp, y, ctaps, Cout, S=S, xf=xf, stats=stats, tile_hint=hint, addend=ad, stats_slots=slots)
     nbytes = x.numel() * 2 + y.numel() * 2
-    flops = 2.0 * N * HW * HW * Cin * Cout * k * k
+    flops = 2.0 * N * (HW // S) * (HW // S) * Cin * Cout * k * k
 elif what.startswith("wgrad"):
     HW, Cin, Cout, k = cfgs[what]
     x, g = mk(N, HW, HW, Cin), mk(N, HW, HW, Cout)
@@ -136,6 +143,8 @@ else:
 for _ in range(3):
     fn()
 torch.cuda.synchronize()
+if what.startswith("conv"):
+    print("   kernel:", ops.last_conv_kernel())
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(iters):

@@ -15,6 +15,9 @@ cd $R
 python tools/timeline.py $O/prof_$TAG > $O/${TAG}_two_stream_timeline.txt
 cp $(ls $O/prof_$TAG/*/*kernel_stats.csv | head -1) $O/${TAG}_bench_kernel_stats.csv
 rm -rf $O/prof_$TAG
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_i_$TAG -- python3 $R/tools/inferprobe.py > $O/${TAG}_infer.log 2>&1
+cp $(ls $O/prof_i_$TAG/*/*kernel_stats.csv | head -1) $O/${TAG}_infer_kernel_stats.csv
+rm -rf $O/prof_i_$TAG
 echo "trace done"
 cd /tmp
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_f -o f -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-breakdown --no-infer --no-extra-legs > $O/${TAG}_pmc_f.log 2>&1
@@ -25,4 +28,6 @@ rm -rf $O/pmc_f $O/pmc_w
 echo "pmc done"
 UBR_PLAN=0 python tools/hostprobe.py > $O/${TAG}_hostprobe.txt 2>&1
 UBR_PLAN=1 python tools/hostprobe.py >> $O/${TAG}_hostprobe.txt 2>&1
+python tools/fwdprobe.py > $O/${TAG}_fwdprobe.txt 2>/dev/null
+python tools/check_store_hazard.py > $O/${TAG}_store_hazard_scan.txt 2>&1
 cat $O/${TAG}_hostprobe.txt

@@ -34,6 +34,7 @@ struct ConvK {
   int ntaps, S, iy0, ix0, OH, OW;
   int dymin, dxmin, HH, HW;
   int tiles_x, tiles_y;
+  unsigned tx_magic, ty_magic;                   // ceil(2^32 / tiles): the tile decomposition is two scalar multiply-highs
   int nunits, steps;
   int pixb;                                      // LDS bytes per halo pixel
   unsigned rw, rw_magic;                         // items per halo row and ceil(2^32/rw)
@@ -176,6 +177,7 @@ template <typename T> __device__ __forceinline__ void store_frag_pair(char* p0, 
 }
 
 typedef __attribute__((ext_vector_type(2))) unsigned ubr_u2;
+__device__ __forceinline__ unsigned udiv_magic(unsigned n, unsigned magic) { return magic == 0u ? n : __umulhi(n, magic); }
 
 // 16-byte buffer store with a scalar offset.  gfx950 reads a store's data registers over several cycles; a VALU write to them in the
 // next instruction slot corrupts what the store sends (observed: the second dword of lanes 12-15 of each 16-lane row).  hipcc (ROCm 7.2)
@@ -215,11 +217,18 @@ __global__ __launch_bounds__(256, ((NT == 4 && FW <= 2 && !PIPE) ? 4 : 2)) void 
   const int tap0 = k.ptap0[ph], p_nunits = k.pnunits[ph], p_steps = k.psteps[ph];
   char* const yb = k.y + k.pyoff[ph];
   const char* const adb = k.ad != nullptr ? k.ad + k.paoff[ph] : nullptr;
-  int t = blockIdx.x;
-  const int tx = t % k.tiles_x; t /= k.tiles_x;
-  const int ty = t % k.tiles_y;
-  const int n = t / k.tiles_y;
+  const unsigned tile_l = blockIdx.x;
+  const unsigned tile_r = udiv_magic(tile_l, k.tx_magic);
+  const int tx = (int)(tile_l - tile_r * (unsigned)k.tiles_x);
+  const int n = (int)udiv_magic(tile_r, k.ty_magic);
+  const int ty = (int)(tile_r - (unsigned)n * (unsigned)k.tiles_y);
   const int n0 = blockIdx.y * TN;
+  // The tap tables are built from per-tap argument bytes indexed by LANE, i.e. memory loads: requested here, ahead of the halo
+  // loads, and consumed after those have been issued (in-kernel stamps, 16x128x128x64 -> 64: the two table loops cost 4-6 k of
+  // the workgroup's 11.5 k prologue cycles, two dependent round trips behind the halo issue).
+  // (unconditional loads with a clamped index: a load inside a branch is waited for where the branch rejoins)
+  const int tb_tap = min(tap0 + (tid >> k.lgUPB), k.ntaps - 1);
+  const int tb_dy = k.dy[tb_tap], tb_dx = k.dx[tb_tap], tb_wt = k.wt[tb_tap];
   const int oy0 = ty * TH, ox0 = tx * TW;
   const int hy0 = oy0 * k.S + k.iy0 + k.dymin, hx0 = ox0 * k.S + k.ix0 + k.dxmin;
 
@@ -259,25 +268,34 @@ __global__ __launch_bounds__(256, ((NT == 4 && FW <= 2 && !PIPE) ? 4 : 2)) void 
       }
     }
   }
-  for (int u = tid; u < 4 * k.steps; u += 256) {
-    int off = 0;
+#ifdef UBR_CONV_STAMPS
+  const unsigned long long t_p1 = __builtin_amdgcn_s_memtime();
+#endif
+  // tbl: LDS offset of a K unit's tap window; wsrc: its weight-slab source index (16-byte items, cin block 0, channel 0; -1 = padding)
+  int* wsrc = tbl + 4 * k.steps;
+  if (tid < 4 * k.steps) {
+    const int c = tid & (k.UPB - 1);
+    const bool in = tid < p_nunits;
+    tbl[tid] = in ? ((tb_dy - k.dymin) * k.HW + (tb_dx - k.dxmin)) * k.pixb + c * 16 : 0;
+    wsrc[tid] = in ? (tb_wt * k.CU + c) * k.Cout_pad : -1;
+  }
+  for (int u = tid + 256; u < 4 * k.steps; u += 256) {       // (more than 256 K units: 64 taps x 4-unit blocks)
+    int off = 0, v = -1;
     if (u < p_nunits) {
       const int tap = tap0 + (u >> k.lgUPB), c = u & (k.UPB - 1);
       off = ((k.dy[tap] - k.dymin) * k.HW + (k.dx[tap] - k.dxmin)) * k.pixb + c * 16;
+      v = ((int)k.wt[tap] * k.CU + c) * k.Cout_pad;
     }
     tbl[u] = off;
-  }
-  // per-unit weight-slab source index (in 16-byte items, cin block 0, channel 0): -1 for zero padding units
-  int* wsrc = tbl + 4 * k.steps;
-  for (int u = tid; u < 4 * k.steps; u += 256) {
-    int v = -1;
-    if (u < p_nunits) {
-      const int tap = tap0 + (u >> k.lgUPB), cc = u & (k.UPB - 1);
-      v = ((int)k.wt[tap] * k.CU + cc) * k.Cout_pad;
-    }
     wsrc[u] = v;
   }
+#ifdef UBR_CONV_STAMPS
+  const unsigned long long t_p2 = __builtin_amdgcn_s_memtime();
+#endif
   __syncthreads();
+#ifdef UBR_CONV_STAMPS
+  const unsigned long long t_p3 = __builtin_amdgcn_s_memtime();
+#endif
 
   f32x4 acc[FW][NT];
 #pragma unroll
@@ -429,6 +447,7 @@ __global__ __launch_bounds__(256, ((NT == 4 && FW <= 2 && !PIPE) ? 4 : 2)) void 
     if (k.stamps != nullptr && tid == 0) {
       unsigned long long* o = k.stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16;
       o[0] = tS; o[1] = tL; o[2] = tC; o[3] = tB; o[6] = tW; o[4] = t_ - t_begin; o[5] = t_begin; o[7] = t_entry; o[8] = t_;
+      o[10] = t_p1; o[14] = t_p2; o[15] = t_p3;
     }
 #endif
   } else
@@ -814,7 +833,6 @@ struct ThinK {
 
 // exact unsigned division of small operands by a runtime divisor: magic = ceil(2^32 / d) for d >= 2 (valid while n * d < 2^32);
 // d == 1 has no 32-bit magic and is encoded as 0
-__device__ __forceinline__ unsigned udiv_magic(unsigned n, unsigned magic) { return magic == 0u ? n : __umulhi(n, magic); }
 
 // ROW7 (7x7 layers over 16 channels, 16x32-pixel tile, FW = 8): a wave owns FOUR output rows of two 16-pixel fragments and
 // walks the 4 + 6 input rows once per horizontal tap pair.  The halo fragment of input row r is the operand of output row
@@ -1929,7 +1947,8 @@ int try_thin(const ConvK& c, dim3 grid, hipStream_t st, int* rc) {
   if (g.x > cap && cap > 0) g.x = cap;
   g_last_conv_cfg[3] = 2;
   const bool xf = c.in_scale != nullptr;
-  snprintf(g_last_conv_name, sizeof(g_last_conv_name), "conv_thin_kernel<%s, %d, %d, %d, %d, %s, %s>", sizeof(T) == 4 ? "float" : (std::is_same<T, bf16_t>::value ? "bf16_t" : "f16_t"),
+  // (the full template argument list, as rocprofv3 prints the symbol)
+  snprintf(g_last_conv_name, sizeof(g_last_conv_name), "conv_thin_kernel<%s, %d, %d, %d, %d, %s, %s, false, 0>", sizeof(T) == 4 ? "float" : (std::is_same<T, bf16_t>::value ? "bf16_t" : "f16_t"),
            FW, NT, TWF, c.UPB, xf ? "true" : "false", c.epilogue == 1 ? "true" : "false");
   if (ext != 0)
     snprintf(g_last_conv_name, sizeof(g_last_conv_name), "conv_thin_kernel<%s, %d, %d, %d, %d, false, false, %s, %d>", sizeof(T) == 4 ? "float" : (std::is_same<T, bf16_t>::value ? "bf16_t" : "f16_t"),
@@ -1937,7 +1956,7 @@ int try_thin(const ConvK& c, dim3 grid, hipStream_t st, int* rc) {
   if constexpr (FW == 8 && NT == 1 && sizeof(T) == 2) {
     if (row7) {
       if (ext == 0)
-      snprintf(g_last_conv_name, sizeof(g_last_conv_name), "conv_thin_kernel<%s, 8, 1, 2, 2, %s, %s, true>", std::is_same<T, bf16_t>::value ? "bf16_t" : "f16_t",
+      snprintf(g_last_conv_name, sizeof(g_last_conv_name), "conv_thin_kernel<%s, 8, 1, 2, 2, %s, %s, true, 0>", std::is_same<T, bf16_t>::value ? "bf16_t" : "f16_t",
                xf ? "true" : "false", c.epilogue == 1 ? "true" : "false");
       if (c.epilogue == 1) *rc = xf ? launch_thin<T, 8, 1, 2, 2, true, true, true>(k, g, lds, st) : launch_thin<T, 8, 1, 2, 2, false, true, true>(k, g, lds, st);
       else if (ext == 1) *rc = launch_thin<T, 8, 1, 2, 2, false, false, true, 1>(k, g, lds, st);
@@ -2298,6 +2317,7 @@ extern "C" int ubr_conv(const ubr_conv_desc* d, void* stream) {
   k.ntaps = d->ntaps; k.S = d->S; k.iy0 = d->iy0; k.ix0 = d->ix0; k.OH = d->OH; k.OW = d->OW;
   k.dymin = dymin; k.dxmin = dxmin; k.HH = best.HH; k.HW = best.HW;
   k.tiles_x = best.tiles_x; k.tiles_y = best.tiles_y;
+  k.tx_magic = magic_u32((unsigned)best.tiles_x); k.ty_magic = magic_u32((unsigned)best.tiles_y);
   k.nunits = eff_ntaps(d) * best.UPB; k.steps = best.steps; k.pixb = best.pixb;
   for (int p = 0; p < 4; ++p) {
     const bool on = p < nphase;

@@ -328,32 +328,28 @@ class WgradWorkspace:
             self.buf = torch.empty(max(n, 1 << 20), dtype=torch.float32, device=device)
         return self.buf
 
-    # slabs that must outlive the launch (their sums are deferred to a batched reduction): a bump arena, reset by release()
-    def hold(self, nbytes: int, device) -> torch.Tensor:
+    # slabs that must outlive the launch (their sums are deferred to a batched reduction): one bump arena PER STREAM, reset by
+    # release().  Everything that touches a stream's arena is ordered by that stream; a shared arena would let a launch on one
+    # stream overwrite slabs a batched sum on the other stream is still reading.
+    def hold(self, nbytes: int, device, stream=None) -> torch.Tensor:
         n = ((nbytes + 3) // 4 + 63) // 64 * 64
-        a = getattr(self, "arena", None)
-        if a is None or a.device != device or self.arena_off + n > a.numel():
+        key = 0 if stream is None else stream.cuda_stream
+        ar = self.__dict__.setdefault("_arenas", {})
+        a = ar.get(key)
+        if a is None or a[0].device != device or a[1] + n > a[0].numel():
             if a is not None:
-                self.arena_old.append(a)          # pending items still point into it
-            self.arena = a = torch.empty(max(2 * n, 64 << 20), dtype=torch.float32, device=device)
-            self.arena_off = 0
-        t = a[self.arena_off:self.arena_off + n]
-        self.arena_off += n
+                self.__dict__.setdefault("_arena_old", []).append(a[0])      # pending items still point into it
+            a = ar[key] = [torch.empty(max(2 * n, 64 << 20), dtype=torch.float32, device=device), 0]
+        t = a[0][a[1]:a[1] + n]
+        a[1] += n
         return t
 
-    def release(self):
-        self.arena_off = 0
+    def release(self, stream=None):
+        a = self.__dict__.get("_arenas", {}).get(0 if stream is None else stream.cuda_stream)
+        if a is not None:
+            a[1] = 0
         if not self.pin:
-            self.arena_old.clear()
-
-    arena = None
-    arena_off = 0
-
-    @property
-    def arena_old(self):
-        if "_arena_old" not in self.__dict__:
-            self.__dict__["_arena_old"] = []
-        return self.__dict__["_arena_old"]
+            self.__dict__.get("_arena_old", []).clear()
 
 
 class ReduceBatch:
@@ -392,7 +388,7 @@ class ReduceBatch:
                 e1.record(stream)
                 _prof.records.append(meta + (e0, e1))
         self.items = []
-        self.ws.release()
+        self.ws.release(stream)
 
 
 _TAP_CACHE_W = {}
@@ -434,7 +430,7 @@ def wgrad(x: torch.Tensor, g: torch.Tensor, taps, dst: torch.Tensor, sm: int, sk
     nsplit, nbytes = C.c_int32(0), C.c_int64(0)
     lib = L.lib()
     L.check(lib.ubr_wgrad_plan(C.byref(d), C.byref(nsplit), C.byref(nbytes)), "wgrad_plan")
-    slabs = ws.get(nbytes.value, x.device) if defer is None else ws.hold(nbytes.value, x.device)
+    slabs = ws.get(nbytes.value, x.device) if defer is None else ws.hold(nbytes.value, x.device, stream)
     if stream is not None:
         # the workspace is grow-only: when a later call replaces it, the caching allocator must not recycle the old block
         # for the compute stream while this (side-stream) launch still reads it
