@@ -1,6 +1,4 @@
 #!/bin/bash
-echo "== default"; python tools/reprocheck.py 3 2>/dev/null
-echo "== UBR_DEFER_REDUCE=0"; UBR_DEFER_REDUCE=0 python tools/reprocheck.py 3 2>/dev/null
-echo "== UBR_WGRAD_PC=0"; UBR_WGRAD_PC=0 python tools/reprocheck.py 3 2>/dev/null
-echo "== UBR_CONV_FAST_EPI=0"; UBR_CONV_FAST_EPI=0 python tools/reprocheck.py 3 2>/dev/null
-echo "== UBR_WGRAD_STREAM=0"; UBR_WGRAD_STREAM=0 python tools/reprocheck.py 3 2>/dev/null
+B="python bench.py --steps 40 --warmup 5 --no-infer --no-cpu-baseline --no-extra-legs --no-breakdown"
+for v in 64 32 16 64 32 16; do echo -n "UBR_PHASE_MIN_C=$v "; UBR_PHASE_MIN_C=$v $B 2>/dev/null | python tools/benchline.py; done
+for v in 64 32 16; do echo -n "infer UBR_PHASE_MIN_C=$v "; UBR_PHASE_MIN_C=$v python tools/inferprobe.py 2>/dev/null | cut -c1-200; done
