@@ -214,6 +214,43 @@ def test_conv_training_epilogues(dt, shape):
         assert torch.equal(y3, y2)
 
 
+@pytest.mark.parametrize("dt", DTS)
+def test_wgrad_slab_sums_batched_equal_single_launches(dt):
+    """ubr_wgrad_reduce_batched: the slab sums of several weight gradients in one launch (ops.ReduceBatch, as the executor issues
+    them once per backward stage) are bitwise the sums of one ubr_wgrad_reduce launch each -- few slabs (the one-thread-per-element
+    form), many slabs (four-wave form), a tap subset scattered into a larger kernel window, more than 16 items (two launches)."""
+    ws = ops.WgradWorkspace()
+    batch = ops.ReduceBatch(ws)
+    cases = [(2, 32, 32, 64, 64, 3), (1, 64, 64, 16, 16, 3), (2, 16, 16, 128, 64, 1), (1, 48, 32, 32, 16, 3), (2, 8, 8, 256, 256, 3)]
+    cases = cases * 4                        # 20 items: more than UBR_REDUCE_BATCH
+    singles, batched, keep = [], [], []
+    for i, (N, H, W, Cin, Cout, k) in enumerate(cases):
+        x = nhwc(rnd(dt, gen(N, Cin, H, W, seed=100 + i)), dt)
+        g = nhwc(rnd(dt, gen(N, Cout, H, W, seed=200 + i)), dt)
+        taps = ops.conv_taps(k, 1, k // 2)
+        if i % 5 == 3:
+            taps = taps[::2]                 # a subset of the window (as the phases of a transposed conv)
+        a = torch.full((Cout, Cin, k, k), 7.0, device=DEV)
+        b = torch.full((Cout, Cin, k, k), 7.0, device=DEV)
+        ops.wgrad(x, g, taps, a, Cin * k * k, k * k, Cout, Cin, ops.WgradWorkspace())
+        ops.wgrad(x, g, taps, b, Cin * k * k, k * k, Cout, Cin, ws, defer=batch)
+        singles.append(a); batched.append(b); keep.append((x, g))
+    assert len(batch.items) == len(cases)
+    batch.flush()
+    assert not batch.items
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(singles, batched)):
+        assert torch.equal(a, b), "item %d" % i
+    # an accumulating call flushes what is pending first and then sums on its own
+    a = singles[0].clone()
+    x, g = keep[0]
+    N, H, W, Cin, Cout, k = cases[0]
+    ops.wgrad(x, g, ops.conv_taps(k, 1, 1), a, Cin * k * k, k * k, Cout, Cin, ws, accumulate=True, defer=batch)
+    torch.cuda.synchronize()
+    assert not batch.items
+    assert torch.equal(a, singles[0] + singles[0])
+
+
 @pytest.mark.parametrize("dt", DTS + [torch.float16])
 @pytest.mark.parametrize("shape", [(2, 16, 16, 128, 64), (1, 8, 24, 512, 256), (2, 12, 20, 64, 64)])
 def test_conv_phases_equal_one_launch_per_phase(dt, shape):
