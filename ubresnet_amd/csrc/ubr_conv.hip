@@ -829,6 +829,9 @@ struct ThinK {
   const char* bc; long bc_sn; int bc_sy, bc_sx; unsigned bc_bytes;
   const float *bmean, *bscale, *bshift, *binvstd;
   int nslots;
+  // several output phases from ONE staged halo (transposed conv k4 s2 p1: the four phases share the 3x3 input neighbourhood):
+  // phase ph walks K-steps [pstep0, pstep0 + psteps) of the tap table and stores at byte offset pyoff from the output view
+  int nphase, pstep0[4], psteps[4], pyoff[4];
 };
 
 // exact unsigned division of small operands by a runtime divisor: magic = ceil(2^32 / d) for d >= 2 (valid while n * d < 2^32);
@@ -1125,6 +1128,13 @@ __global__ __launch_bounds__(256, ((ROW7 || (EXT == 1 && NT == 2)) ? 2 : 3)) voi
             else cv4[i][j] = __builtin_amdgcn_raw_buffer_load_b128(cr, vo_c[j] + (i % TWF) * 16 * k.bc_sx, so, 0);
           }
       }
+      // (phased launches: every phase of this fragment group from the same halo, one after the other)
+      const int nph = (ROW7 || LSM || EXT != 0) ? 1 : k.nphase;
+#pragma unroll 1
+      for (int ph = 0; ph < nph; ++ph) {
+      const int s_lo = nph > 1 ? k.pstep0[ph] : 0;
+      const int s_cnt = nph > 1 ? k.psteps[ph] : k.steps;
+      const int y_ph = nph > 1 ? k.pyoff[ph] : 0;
       f32x4 acc[FH][NT];
 #pragma unroll
       for (int i = 0; i < FH; ++i)
@@ -1155,12 +1165,12 @@ __global__ __launch_bounds__(256, ((ROW7 || (EXT == 1 && NT == 2)) ? 2 : 3)) voi
           }
         }
       } else {
-      int off_n = tbl[q];
+      int off_n = tbl[4 * s_lo + q];
       uint4 wf_n[NT];
 #pragma unroll
-      for (int j = 0; j < NT; ++j) wf_n[j] = *reinterpret_cast<const uint4*>(wl + ((q * TN) + j * 16 + l16) * 16);
-      const int nsteps = (k.dbg & 2) ? 1 : k.steps;
-      for (int s = 0; s < nsteps; ++s) {
+      for (int j = 0; j < NT; ++j) wf_n[j] = *reinterpret_cast<const uint4*>(wl + (((4 * s_lo + q) * TN) + j * 16 + l16) * 16);
+      const int nsteps = s_lo + ((k.dbg & 2) ? 1 : s_cnt);
+      for (int s = s_lo; s < nsteps; ++s) {
         const char* pa = hb + off_n;
         uint4 wf[NT];
 #pragma unroll
@@ -1238,7 +1248,7 @@ __global__ __launch_bounds__(256, ((ROW7 || (EXT == 1 && NT == 2)) ? 2 : 3)) voi
               for (int r = 0; r < 4; ++r) { s1[j][r] += v[h][r]; s2[j][r] += v[h][r] * v[h][r]; }
             }
           }
-          const int so = ybase + ((g0 + i) / TWF) * k.y_sy;
+          const int so = ybase + ((g0 + i) / TWF) * k.y_sy + y_ph;
           if constexpr (!LSM) {
             if (k.dbg & 4) {
               if (v[0][0] == 1.2345e-30f && v[1][1] == 1.2345e-30f) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[0][0]), yr, vo_out[j], so, 0);
@@ -1280,6 +1290,7 @@ __global__ __launch_bounds__(256, ((ROW7 || (EXT == 1 && NT == 2)) ? 2 : 3)) voi
           }
         }
       }
+      }   // phases
       UBR_TSTAMP(tE);
     }   // fragment groups
     tile = next;
@@ -1865,7 +1876,19 @@ int try_thin(const ConvK& c, dim3 grid, hipStream_t st, int* rc) {
   constexpr int TH = 4 * FW / TWF, TW = TWF * 16, TN = NT * 16;
   static const bool thin_on = [] { const char* e = getenv("UBR_CONV_THIN"); return !e || atoi(e) != 0; }();
   const int esz = 16 / ET<T>::CPU;
-  if (!thin_on || c.nblk != 1 || c.S != 1 || (c.UPB != 2 && c.UPB != 4) || grid.z > 1) return 0;
+  if (!thin_on || c.nblk != 1 || c.S != 1 || (c.UPB != 2 && c.UPB != 4)) return 0;
+  const int nph = (int)grid.z;
+  int steps_tot = c.steps, nunits_tot = c.nunits;
+  if (nph > 1) {
+    // phases share one staged halo and one tap table: whole K-steps per phase, taps of the phases back to back, plain NHWC output
+    if (nph > 4 || c.ad != nullptr || c.stats != nullptr || c.epilogue != 0 || c.bc != nullptr || c.ad_mask != nullptr) return 0;
+    steps_tot = 0; nunits_tot = 0;
+    for (int p = 0; p < nph; ++p) {
+      if (c.pnunits[p] % 4 || c.ptap0[p] * c.UPB != nunits_tot || c.pyoff[p] < 0 || c.pyoff[p] >= (1L << 30)) return 0;
+      steps_tot += c.psteps[p]; nunits_tot += c.pnunits[p];
+    }
+    if (nunits_tot != c.ntaps * c.UPB) return 0;
+  }
   // ROW7: the full 7x7 tap set over 16 input channels on the 16x32-pixel tile (see conv_thin_kernel)
   int map7[7][7];
   bool row7 = false;
@@ -1899,9 +1922,14 @@ int try_thin(const ConvK& c, dim3 grid, hipStream_t st, int* rc) {
   k.H = c.H; k.W = c.W; k.HW = c.HW; k.nitems = c.HH * (int)c.rw; k.hw_magic = magic_u32((unsigned)c.HW);
   k.tiles_x = c.tiles_x; k.tiles_y = c.tiles_y; k.ntiles = ntiles;
   k.tx_magic = magic_u32((unsigned)c.tiles_x); k.ty_magic = magic_u32((unsigned)c.tiles_y);
-  k.steps = c.steps; k.nunits = c.nunits; k.hy_org = c.iy0 + c.dymin; k.hx_org = c.ix0 + c.dxmin; k.dymin = c.dymin; k.dxmin = c.dxmin;
+  k.steps = steps_tot; k.nunits = nunits_tot; k.hy_org = c.iy0 + c.dymin; k.hx_org = c.ix0 + c.dxmin; k.dymin = c.dymin; k.dxmin = c.dxmin;
+  k.nphase = nph;
+  for (int p = 0, s0 = 0; p < 4; ++p) {
+    k.pstep0[p] = s0; k.psteps[p] = p < nph ? c.psteps[p] : 0; k.pyoff[p] = p < nph ? (int)c.pyoff[p] : 0;
+    s0 += k.psteps[p];
+  }
   k.Cout = c.Cout; k.Cout_pad = c.Cout_pad; k.CU = c.CU; k.OH = c.OH; k.OW = c.OW;
-  k.act = c.act; k.epilogue = c.epilogue; k.wlinear = c.wlinear; k.dbg = c.dbg; k.stamps = c.stamps;
+  k.act = c.act; k.epilogue = c.epilogue; k.wlinear = nph > 1 ? 0 : c.wlinear; k.dbg = c.dbg; k.stamps = c.stamps;
   for (int t = 0; t < c.ntaps; ++t) { k.dy[t] = c.dy[t]; k.dx[t] = c.dx[t]; k.wt[t] = c.wt[t]; }
   // training epilogues: BatchNorm-backward sums (EXT 1) or a ReLU bit mask on the addend (EXT 2); never both (ubr_conv checks)
   const int ext = c.bc != nullptr ? 1 : (c.ad_mask != nullptr ? 2 : 0);
@@ -2162,6 +2190,16 @@ static bool thin_eligible(const ubr_conv_desc* d, int cfg, const Plan& p, bool w
   const int CU = d->Cin / cpu, TH = 4 * c.FW / c.TWF, TW = c.TWF * 16;
   if (p.UPB != CU || d->S != 1 || (p.UPB != 2 && p.UPB != 4)) return false;
   if (d->OH % TH || d->OW % TW) return false;
+  if (d->nphase > 1) {      // (try_thin's conditions for a phased launch)
+    static const bool ph_on = [] { const char* e = getenv("UBR_THIN_PHASES"); return !e || atoi(e) != 0; }();
+    if (!ph_on || d->addend.p != nullptr || d->stats != nullptr || d->epilogue != 0) return false;
+    int t0 = 0;
+    for (int q = 0; q < d->nphase; ++q) {
+      if ((d->phase_ntaps[q] * p.UPB) % 4 || d->phase_tap0[q] != t0) return false;
+      t0 += d->phase_ntaps[q];
+    }
+    if (t0 != d->ntaps) return false;
+  }
   // the row-stationary 7x7 form (ROW7) of the 16x32-pixel tile: try_thin re-checks the tap set
   static const bool row7_on = [] { const char* e = getenv("UBR_CONV_ROW7"); return !e || atoi(e) != 0; }();
   const bool row7 = row7_on && cfg == 0 && esz == 2 && d->ntaps == 49 && p.UPB == 2 && p.HW == TW + 6 && p.HH == TH + 6;
@@ -2271,7 +2309,7 @@ extern "C" int ubr_conv(const ubr_conv_desc* d, void* stream) {
       }
     }
     // thin layers (one cin block, <= 32 output channels): the largest tile the persistent conv_thin_kernel can take wins outright
-    if (d->Cout_pad <= 32 && nphase == 1) {
+    if (d->Cout_pad <= 32) {
       const int g = d->Cout_pad == 32 ? 1 : 2;
       for (int i = 0; i < 4 && !have; ++i) {
         const int cfg = order_by_nt[g][i];

@@ -54,7 +54,7 @@ _DEFER_REDUCE = _os.environ.get("UBR_DEFER_REDUCE", "1") != "0"     # weight-gra
 _TAIL_FIN = _os.environ.get("UBR_TAIL_FIN", "1") != "0"
 # the four output phases of a transposed conv / of a stride-2 conv's data gradient in ONE launch when the layer has at least this
 # many output channels (narrower layers run on the persistent thin kernel, one launch per phase)
-_PHASE_MIN_C = int(_os.environ.get("UBR_PHASE_MIN_C", "64"))
+_PHASE_MIN_C = int(_os.environ.get("UBR_PHASE_MIN_C", "16"))
 
 
 def _phased(k, pad):
