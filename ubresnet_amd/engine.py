@@ -53,7 +53,8 @@ _WG_AFTER = _os.environ.get("UBR_WGRAD_ORDER", "before") == "after"
 _DEFER_REDUCE = _os.environ.get("UBR_DEFER_REDUCE", "1") != "0"     # weight-gradient slab sums: one launch per backward stage
 _TAIL_FIN = _os.environ.get("UBR_TAIL_FIN", "1") != "0"
 # the four output phases of a transposed conv / of a stride-2 conv's data gradient in ONE launch when the layer has at least this
-# many output channels (narrower layers run on the persistent thin kernel, one launch per phase)
+# many output channels (conv_igemm_kernel: a phase per blockIdx.z; conv_thin_kernel, Cin <= 32 without an addend: a phase loop over
+# one staged halo)
 _PHASE_MIN_C = int(_os.environ.get("UBR_PHASE_MIN_C", "16"))
 
 
