@@ -600,7 +600,10 @@ static int wgrad_plan(const ubr_wgrad_desc* d, WPlan* p) {
   // One workgroup per CU.  More would finish a lone weight gradient sooner, but these kernels run on the side stream
   // beside the dgrad chain and their long-lived workgroups (200+ VGPRs, grid-stride over tiles) must leave register
   // file and LDS for the compute stream's kernels: 512 / 1024 workgroups cost the step 5 % (1077 vs 1136 img/s).
-  static const int tgt_n = [] { const char* e = getenv("UBR_WGRAD_TARGET_N"); return e ? atoi(e) : 256; }();
+  // (round 3: the wide, channel-split kernels -- producer/consumer, eight waves, all of a CU's registers -- on HALF the CUs: 128
+  // workgroups leave the other 128 CUs to the compute stream outright instead of time-slicing all 256, and halve the slabs:
+  // 11.74 -> 11.39 ms/step; 96: 11.77, 160: 11.49, 64: 12.5.  The K-split kernels of the thin layers stay at 256: fewer is slower.)
+  static const int tgt_n = [] { const char* e = getenv("UBR_WGRAD_TARGET_N"); return e ? atoi(e) : 128; }();
   static const int tgt_k = [] { const char* e = getenv("UBR_WGRAD_TARGET_K"); return e ? atoi(e) : 256; }();
   // an exclusive launch (the stem's weight gradient closes the backward pass: the compute stream is idle by then) takes three
   // workgroups per CU: 188 -> 88 us for the 7-tap 16-channel layer at 16x512x512
